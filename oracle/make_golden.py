@@ -1,0 +1,268 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.json.gz by running the REAL reference worker.
+
+TEST INFRASTRUCTURE ONLY; runs only in the build container (needs
+/root/reference, which never travels to the GPU box).  The reference is
+imported unmodified from where it lies; `Bio.bgzf` (biopython is not
+installed here) is replaced by an empty stub module because
+pop_factory.py:13 imports it at module level -- the hot path
+(pop_factory.py:471-513) never touches it.
+
+Two kinds of expected output are recorded per case:
+  lines_mt      the unmodified worker after numpy.random.seed(seed)
+  lines_philox  the same worker with numpy.random.rand replaced by the
+                Philox4x32-10 draw of DESIGN.md (row r, draw n -> word n&3 of
+                philox(ctr=(n>>2,0,r_lo,r_hi), key=seed) scaled by 2^-32)
+
+A fixture is data only: inputs (SNP tuples, sample table) and the bytes the
+reference produced for them.
+"""
+import gzip
+import json
+import os
+import random
+import sys
+import tempfile
+import types
+
+import numpy
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(HERE)
+REF = os.environ.get("DNAF_REFERENCE", "/root/reference")
+GOLD = os.path.join(REPO, "tests", "golden")
+
+sys.path.insert(0, REPO)
+from oracle import oracle as orc  # noqa: E402  (numpy Philox draw function)
+
+
+def import_reference():
+    sys.dont_write_bytecode = True
+    bio = types.ModuleType("Bio")
+    bgzf = types.ModuleType("Bio.bgzf")
+    bgzf.BgzfWriter = object  # never instantiated by the hot path
+    bio.bgzf = bgzf
+    sys.modules["Bio"] = bio
+    sys.modules["Bio.bgzf"] = bgzf
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+    import pop_factory  # the reference module
+
+    pop_factory.time.sleep = lambda *_a, **_k: None  # worker's exit sleep, pop_factory.py:512
+    return pop_factory
+
+
+class FakePipe:
+    def __init__(self):
+        self.msgs = []
+
+    def send(self, m):
+        self.msgs.append(m)
+
+    def close(self):
+        pass
+
+
+def run_worker(pf_mod, fam_data, snps):
+    pf = pf_mod.PopulationFactory(output_path=tempfile.gettempdir())
+    pipe = FakePipe()
+    pf.queue_vcf_snps(fam_data, list(enumerate(snps, 1)), pipe)
+    assert pipe.msgs[-1] == "DONE"
+    nums = [m[0] for m in pipe.msgs[:-1]]
+    assert nums == list(range(1, len(snps) + 1))
+    return [m[1] for m in pipe.msgs[:-1]]
+
+
+def run_worker_mt(pf_mod, fam_data, snps, seed):
+    numpy.random.seed(seed)
+    return run_worker(pf_mod, fam_data, snps)
+
+
+def run_worker_philox(pf_mod, fam_data, snps, seed, row0=0):
+    state = {"row": row0}
+    real_rand = numpy.random.rand
+
+    def philox_rand(n):
+        u = orc.philox_row_uniforms(seed, state["row"], n)
+        state["row"] += 1
+        return u
+
+    pf_mod.numpy.random.rand = philox_rand
+    try:
+        return run_worker(pf_mod, fam_data, snps)
+    finally:
+        pf_mod.numpy.random.rand = real_rand
+
+
+def make_snp(pf_mod, sid, chrom, pos, tuples):
+    s = pf_mod.SNPTuples(sid, chrom, pos)
+    for letter, cum in tuples:
+        s.add_tuple(letter, cum)
+    return s
+
+
+def make_samples(pf_mod, spec):
+    """spec: list of (iid, sex, is_control, carried dict or None)"""
+    return [pf_mod.SampleInfo(i + 1, iid, 0, 0, sex, ctrl, carried) for i, (iid, sex, ctrl, carried) in enumerate(spec)]
+
+
+def dump(name, snps, spec, seed, lines_mt, lines_philox, extra=None):
+    doc = {
+        "name": name,
+        "seed": seed,
+        "snps": [[s.id, s.chromosome, s.position, [[t[0], float(t[1])] for t in s.tuples]] for s in snps],
+        "samples": [[iid, sex, bool(ctrl), (sorted(int(k) for k in carried) if carried is not None else None)]
+                    for (iid, sex, ctrl, carried) in spec],
+        "lines_mt": lines_mt,
+        "lines_philox": lines_philox,
+    }
+    if extra:
+        doc.update(extra)
+    path = os.path.join(GOLD, name + ".json.gz")
+    with gzip.GzipFile(path, "wb", compresslevel=9, mtime=0) as f:
+        f.write(json.dumps(doc, separators=(",", ":")).encode())
+    print("wrote %s (%d rows x %d samples, %d bytes)" % (path, len(snps), len(spec), os.path.getsize(path)))
+
+
+def case_mixed(pf_mod, name, n_rows, S, seed, rs):
+    """All chromosome classes, both sexes, controls/cases, forced cells (incl. female-on-Y), multi-allelic rows."""
+    chroms = [str(c) for c in range(1, 23)] + ["X", "Y", "MT"]
+    letters = ["A", "C", "G", "T"]
+    snps = []
+    for j in range(n_rows):
+        chrom = chroms[j % len(chroms)] if j < 2 * len(chroms) else chroms[rs.randint(0, len(chroms))]
+        kind = j % 11
+        perm = list(rs.permutation(letters))
+        maf = 0.005 * rs.randint(1, 100)
+        if kind == 7:  # three alleles
+            tuples = [(perm[0], 0.70), (perm[1], 0.90), (perm[2], 1.0)]
+        elif kind == 9:  # four alleles
+            tuples = [(perm[0], 0.55), (perm[1], 0.80), (perm[2], 0.93), (perm[3], 1.0)]
+        elif kind == 10 and j % 22 == 10:  # single tuple: ALT printed as REF
+            tuples = [(perm[0], 1.0)]
+        else:
+            tuples = [(perm[0], 1 - maf), (perm[1], 1.0)]
+        sid = 1000 + ((j * 7919) % 100003)  # ids not monotone in row order
+        snps.append(make_snp(pf_mod, sid, chrom, int(rs.randint(0, 250000000)), tuples))
+    ids = [s.id for s in snps]
+    y_ids = [s.id for s in snps if s.chromosome == "Y"]
+    n_ctrl = S // 2
+    spec = []
+    for i in range(S):
+        ctrl = i < n_ctrl
+        sex = 1 if rs.rand() <= 0.5 else 2
+        carried = None
+        if not ctrl:
+            k = int(rs.randint(0, 6))
+            chosen = [int(x) for x in rs.choice(ids, size=k, replace=False)] if k else []
+            if y_ids and i % 3 == 0:
+                chosen.append(int(y_ids[i % len(y_ids)]))  # female case "carrying" a Y SNP -> '.' wins (Q7)
+            carried = {c: 0.5 for c in chosen}
+        spec.append((100001 + i if ctrl else 500001 + i, sex, ctrl, carried))
+    fam = make_samples(pf_mod, spec)
+    dump(name, snps, spec, seed, run_worker_mt(pf_mod, fam, snps, seed), run_worker_philox(pf_mod, fam, snps, seed))
+
+
+def case_threshold_equality(pf_mod):
+    """Rolls exactly equal to a threshold pick the LOWER index (`>=`), in both RNG modes."""
+    S, seed = 12, 4242
+    spec = [(100001 + i, 1 + (i % 2), True, None) for i in range(S)]
+    fam = make_samples(pf_mod, spec)
+    # MT mode: thresholds taken from the very doubles the worker will draw
+    numpy.random.seed(seed)
+    d = [numpy.random.rand(2 * S) for _ in range(4)]
+    snps_mt = [
+        make_snp(pf_mod, 1, "1", 100, [("A", float(d[0][6])), ("C", 1.0)]),
+        make_snp(pf_mod, 2, "2", 200, [("G", float(d[1][9])), ("T", 1.0)]),
+        make_snp(pf_mod, 3, "3", 300, [("A", float(numpy.nextafter(d[2][4], 0.0))), ("T", 1.0)]),
+        make_snp(pf_mod, 4, "4", 400, [("A", float(d[3][0])), ("C", float(d[3][1])), ("G", 1.0)]),
+    ]
+    lines_mt = run_worker_mt(pf_mod, fam, snps_mt, seed)
+    p = [orc.philox_row_uniforms(seed, r, 2 * S) for r in range(4)]
+    snps_ph = [
+        make_snp(pf_mod, 1, "1", 100, [("A", float(p[0][6])), ("C", 1.0)]),
+        make_snp(pf_mod, 2, "2", 200, [("G", float(p[1][9])), ("T", 1.0)]),
+        make_snp(pf_mod, 3, "3", 300, [("A", float(numpy.nextafter(p[2][4], 0.0))), ("T", 1.0)]),
+        make_snp(pf_mod, 4, "4", 400, [("A", float(p[3][0])), ("C", float(p[3][1])), ("G", 1.0)]),
+    ]
+    lines_ph = run_worker_philox(pf_mod, fam, snps_ph, seed)
+    dump("threshold_equality_mt", snps_mt, spec, seed, lines_mt, None)
+    dump("threshold_equality_philox", snps_ph, spec, seed, None, lines_ph)
+
+
+def case_ragged(pf_mod):
+    """Sample counts around every packing boundary, including S = 0 (line = prefix + newline)."""
+    rs = numpy.random.RandomState(99)
+    for S in (0, 1, 2, 3, 4, 5, 15, 16, 17, 31, 33, 63, 64, 65, 255, 257):
+        snps = [
+            make_snp(pf_mod, 11, "1", 12345, [("A", 0.8), ("G", 1.0)]),
+            make_snp(pf_mod, 12, "X", 777, [("C", 0.6), ("T", 1.0)]),
+            make_snp(pf_mod, 13, "Y", 31, [("G", 0.5), ("A", 1.0)]),
+            make_snp(pf_mod, 14, "MT", 9, [("T", 0.9), ("C", 1.0)]),
+            make_snp(pf_mod, 15, "22", 50806828, [("T", 0.3), ("C", 0.6), ("A", 1.0)]),
+        ]
+        spec = []
+        for i in range(S):
+            ctrl = i % 2 == 0
+            spec.append((100001 + i, 1 if rs.rand() <= 0.5 else 2, ctrl, None if ctrl else ({12: 1.0, 13: 1.0} if i % 4 == 1 else {})))
+        fam = make_samples(pf_mod, spec)
+        seed = 7 + S
+        dump("ragged_S%d" % S, snps, spec, seed, run_worker_mt(pf_mod, fam, snps, seed),
+             run_worker_philox(pf_mod, fam, snps, seed))
+
+
+def case_full_flow(pf_mod):
+    """The reference's own feeders end to end (SnpFactory -> sort -> deleterious.yml picks -> fam -> worker),
+    recorded so the host side can be checked against it: SNP list, deleterious.json lines, fam lines,
+    pop_deleterious.txt, header, numpy MT state at worker entry, and the body lines."""
+    tmp = tempfile.mkdtemp(prefix="dnaf_golden_")
+    numpy.random.seed(20261)
+    random.seed(97531)
+    cwd = os.getcwd()
+    os.chdir(REF)
+    try:
+        pf = pf_mod.PopulationFactory(num_processes=1, generate_snps=True, male_odds=0.5,
+                                      deleterious_config=os.path.join(REF, "deleterious.yml"), output_path=tmp)
+        fac = pf_mod.SnpFactory.init_from_cdf_file()
+        pf.ordered_snps = fac.random_snp_tuples(400, min_maf=0.01)
+        pf.ordered_snps.sort(key=lambda x: (x.chromosome, x.position))
+        pf.pick_deleterious_snps(pf.ordered_snps, pf.deleterious_config)
+        groups = pf_mod.PopulationFactory.pick_deleterious_groups(list(pf.deleterious.values()), 60)
+        fam = pf.generate_fam_file(60, 60, 0.5, groups)
+    finally:
+        os.chdir(cwd)
+    st = numpy.random.get_state()
+    assert st[0] == "MT19937"
+    lines_mt = run_worker(pf_mod, fam, pf.ordered_snps)  # continues from the state above
+    spec = [(s.person_id, s.sex, s.is_control, s.deleterious_snps) for s in fam]
+    lines_ph = run_worker_philox(pf_mod, fam, pf.ordered_snps, 20261)
+    header = pf_mod.gen_vcf_header(fam).split("\n")
+    header[1] = "##filedate=FROZEN"
+    extra = {
+        "mt_state_key": [int(x) for x in st[1]],
+        "mt_state_pos": int(st[2]),
+        "deleterious_json": open(os.path.join(tmp, "deleterious.json")).read(),
+        "population_fam": open(os.path.join(tmp, "population.fam")).read(),
+        "pop_deleterious_txt": open(os.path.join(tmp, "pop_deleterious.txt")).read(),
+        "vcf_header": "\n".join(header),
+        "numpy_seed": 20261,
+        "python_random_seed": 97531,
+    }
+    dump("full_flow_120x400", pf.ordered_snps, spec, 20261, lines_mt, lines_ph, extra)
+
+
+def main():
+    os.makedirs(GOLD, exist_ok=True)
+    pf_mod = import_reference()
+    # the reference's own known answers, test/unit/pop_factory_test.py:24-28
+    t = make_snp(pf_mod, 100, "1", 50000, [("G", 0.70), ("A", 0.90), ("T", 1.0)])
+    assert t.pick_allele_index(0.95) == 2 and t.pick_allele_index(0.4) == 0
+    case_mixed(pf_mod, "mixed_64x97", 64, 97, 12345, numpy.random.RandomState(1))
+    case_mixed(pf_mod, "mixed_150x260", 150, 260, 86399, numpy.random.RandomState(2))
+    case_threshold_equality(pf_mod)
+    case_ragged(pf_mod)
+    case_full_flow(pf_mod)
+
+
+if __name__ == "__main__":
+    main()
