@@ -1,0 +1,257 @@
+#!/usr/bin/env python3
+"""Benchmark of the row-generation hot path (BASELINE.json: SNP-rows/s at fixed #samples).
+
+    python bench.py --gpus N --steps K --warmup W
+
+A *step* is one pass of the hot path over one tile of `--tile-rows` SNP rows for all `--samples` samples
+(text + packed 2-bit matrix, both left resident in HBM).  The default workload is BASELINE config 3
+("10k cases + 10k controls x 5M SNPs, -f 0.01"): 20 steps x 250,000 rows = 5M rows per GPU.  With N GPUs every
+rank generates its own 5M-row SNP range of one global table (SNP-range sharding, no collective on the data
+path: weak scaling); `value` = rows all ranks generated / max-over-ranks wall time.
+
+The JSON line also carries `roofline` (algorithmic bytes per launch / mean kernel time from HIP events on the
+launch stream, vs the 8 TB/s HBM peak) and `cpu_baseline` (the CPU oracle on the host cores, rank 0, N=1).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--samples", type=int, default=20000, help="cases + controls (half each)")
+    ap.add_argument("--tile-rows", type=int, default=250000, help="SNP rows per step")
+    ap.add_argument("--table-rows", type=int, default=5000000, help="SNP rows per GPU (tiles cycle through them)")
+    ap.add_argument("--min-maf", type=float, default=0.01)
+    ap.add_argument("--seed", type=int, default=12345, help="row RNG seed")
+    ap.add_argument("--table-seed", type=int, default=20261004, help="seed of the synthetic SNP / sample tables")
+    ap.add_argument("--what", choices=["text+packed", "text", "packed"], default="text+packed")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target duration of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "pmc_traffic.json"),
+                    help="HBM bytes per launch from a rocprofv3 --pmc run of this same command (optional)")
+    return ap.parse_args()
+
+
+def synthetic_samples(S, n_rows_table, snp_ids, rs):
+    """Controls first, then cases (pop_factory.py:357-358); sex ~ Bernoulli(0.5) (:365).  Forced set shaped like
+    the default deleterious.yml: 66 SNPs over 14 group instances; each case belongs to one instance and carries a
+    random subset of its SNPs (select_mutations, pop_factory.py:621-635)."""
+    from dna_factory_amd import capi
+    from dna_factory_amd.tables import SampleTable
+
+    n_ctrl = S // 2
+    flags = (rs.random_sample(S) <= 0.5).astype(np.uint8) * capi.SAMPLE_MALE
+    flags[:n_ctrl] |= capi.SAMPLE_CONTROL
+    group_sizes = [3, 3, 3, 3, 10, 10, 10, 4, 4, 4, 4, 4, 1, 3]  # deleterious.yml:8-68
+    n_slots = sum(group_sizes)
+    slot_ids = rs.choice(snp_ids, size=n_slots, replace=False)
+    bounds = np.concatenate([[0], np.cumsum(group_sizes)])
+    case_group = rs.randint(0, len(group_sizes), size=S - n_ctrl)
+    carriers = [[] for _ in range(n_slots)]
+    for k, g in enumerate(case_group):
+        lo, hi = bounds[g], bounds[g + 1]
+        take = rs.randint(1, hi - lo + 1)
+        for s in rs.choice(np.arange(lo, hi), size=take, replace=False):
+            carriers[s].append(n_ctrl + k)
+    order = np.argsort(slot_ids)
+    off = np.zeros(n_slots + 1, dtype=np.uint64)
+    idx = []
+    for n, s in enumerate(order):
+        idx.extend(sorted(carriers[s]))
+        off[n + 1] = len(idx)
+    return SampleTable(flags, slot_ids[order], off, np.asarray(idx, dtype=np.uint32))
+
+
+def cpu_baseline(tb, st, seed, target_seconds):
+    """Time the CPU oracle (oracle/rowgen_oracle.c, the checker -- never the product) on cores-1 host threads over
+    a bounded prefix of the same workload."""
+    from oracle import oracle as orc
+
+    orc.build()
+    S = len(st)
+    cores = max(1, (os.cpu_count() or 2) - 1)
+    # oracle inputs from the SoA tables
+    def records(lo, hi):
+        rec = np.zeros(hi - lo, dtype=orc.SNP_DTYPE)
+        rec["chrom"] = tb.chrom[lo:hi]
+        rec["position"] = tb.position[lo:hi]
+        rec["id"] = tb.snp_id[lo:hi]
+        rec["ref"] = tb.ref[lo:hi]
+        rec["alt"] = tb.alt[lo:hi]
+        rec["n_alleles"] = tb.n_alleles[lo:hi]
+        rec["cum"][:, :4] = tb.cum[lo:hi]
+        return rec
+
+    from dna_factory_amd import capi
+
+    sex = np.where(st.flags & capi.SAMPLE_MALE, 1, 2).astype(np.uint8)
+    ctrl = ((st.flags & capi.SAMPLE_CONTROL) != 0).astype(np.uint8)
+    per_sample = [[] for _ in range(S)]
+    for k, sid in enumerate(st.forced_ids):
+        for i in st.carrier_idx[int(st.carrier_off[k]): int(st.carrier_off[k + 1])]:
+            per_sample[int(i)].append(int(sid))
+    doff = np.zeros(S + 1, dtype=np.uint64)
+    dids = []
+    for i in range(S):
+        dids.extend(per_sample[i])
+        doff[i + 1] = len(dids)
+    dids = np.asarray(dids, dtype=np.int64)
+    # calibrate on a small sample, then size the run for ~target_seconds
+    n0, dt0 = 8 * cores, 0.0
+    while True:
+        n0 = min(len(tb), n0)
+        t0 = time.perf_counter()
+        orc.generate_threads(records(0, n0), sex, ctrl, doff, dids, seed, cores)
+        dt0 = max(time.perf_counter() - t0, 1e-6)
+        if dt0 >= 0.5 or n0 >= len(tb):
+            break
+        n0 *= 4
+    n = int(min(len(tb), max(n0, n0 * target_seconds / dt0)))
+    rec = records(0, n)
+    t0 = time.perf_counter()
+    orc.generate_threads(rec, sex, ctrl, doff, dids, seed, cores)
+    dt = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "SNP-rows/s", "cores": cores, "kind": "port",
+            "genotypes_per_s": n * S / dt,
+            "sample": "first %d rows x %d samples of the same table, CPU oracle (C restatement of "
+                      "pop_factory.py:471-513, Philox draws) on %d threads, %.1f s" % (n, S, cores, dt)}
+
+
+def main():
+    a = parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != max(a.gpus, 1) and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (a.gpus, world))
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import __graft_entry__ as ge
+
+    if not os.path.exists(os.path.join(ROOT, "dna-factory_amd", "csrc", "libdnaf_hip.so")):
+        ge.build()
+    from dna_factory_amd import capi
+    from dna_factory_amd.genome import synthetic_snp_table
+    from dna_factory_amd.rowgen import RowGenerator
+
+    S = a.samples
+    rows = max(a.table_rows, a.tile_rows)
+    rs = np.random.RandomState(a.table_seed + 1000 * rank)
+    tb = synthetic_snp_table(rows, a.min_maf, rs)
+    st = synthetic_samples(S, rows, tb.snp_id, np.random.RandomState(a.table_seed))  # same samples on every rank
+    gen = RowGenerator(device=local_rank, seed=a.seed)
+    gen.set_samples(st)
+    gen.set_snps(tb, rng_row0=rank * rows)  # this rank's SNP range of the global table
+    what = {"text+packed": capi.OUT_TEXT | capi.OUT_PACKED, "text": capi.OUT_TEXT, "packed": capi.OUT_PACKED}[a.what]
+    n_tiles = max(1, rows // a.tile_rows)
+
+    def step(i):
+        gen.ctx.generate((i % n_tiles) * a.tile_rows, a.tile_rows, what)
+
+    def barrier():
+        gen.ctx.sync()
+        if dist is not None:
+            dist.barrier()
+            import torch
+
+            torch.cuda.synchronize()
+
+    for i in range(a.warmup):
+        step(i)
+    barrier()
+    gen.ctx.timing_begin()
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        step(a.warmup + i)
+    gen.ctx.sync()
+    if dist is not None:
+        import torch
+
+        torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    barrier()
+    kern_ms, n_rec, n_launch = gen.ctx.timing_end()
+    elapsed = t1 - t0
+    if dist is not None:
+        import torch
+
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        # algorithmic bytes of one launch: packed row + text row + 32-byte SNP record, per row
+        tiles_used = [(a.warmup + i) % n_tiles for i in range(a.steps)]
+        text_b = np.mean([gen.ctx.text_bytes(t * a.tile_rows, a.tile_rows) for t in set(tiles_used)])
+        bytes_per_launch = 32.0 * a.tile_rows
+        if what & capi.OUT_TEXT:
+            bytes_per_launch += text_b
+        if what & capi.OUT_PACKED:
+            bytes_per_launch += a.tile_rows * 4.0 * gen.words_per_row
+        mean_kernel_s = (kern_ms / max(n_rec, 1)) * 1e-3
+        achieved = bytes_per_launch / mean_kernel_s / 1e9
+        traffic = None
+        if os.path.exists(a.traffic_json):
+            try:
+                tj = json.load(open(a.traffic_json))
+                if tj.get("samples") == S and tj.get("tile_rows") == a.tile_rows and tj.get("what") == a.what:
+                    traffic = tj.get("hbm_bytes_per_launch")
+            except (OSError, ValueError):
+                pass
+        total_rows = a.steps * a.tile_rows * world
+        out = {
+            "metric": "SNP-rows/sec at fixed #samples",
+            "value": total_rows / elapsed,
+            "unit": "SNP-rows/s",
+            "genotypes_per_s": total_rows * S / elapsed,
+            "n_gpus": world,
+            "steps": a.steps,
+            "warmup": a.warmup,
+            "ms_per_step": elapsed / a.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u32",
+            "data": "synthetic",
+            "config": {"workload": "BASELINE config 3: 10k cases + 10k controls x 5M SNPs, -f 0.01 (per GPU), "
+                                   "streamed in row tiles; outputs resident in HBM",
+                       "samples": S, "tile_rows": a.tile_rows, "table_rows_per_gpu": rows, "min_maf": a.min_maf,
+                       "outputs": a.what, "rng": "philox4x32-10", "seed": a.seed, "table_seed": a.table_seed,
+                       "sharding": "SNP-range per GPU, no collective"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "bytes_per_launch": bytes_per_launch, "kernel_ms_mean": mean_kernel_s * 1e3,
+                         "launches_timed": n_rec, "kernel": "rowgen_kernel",
+                         "draws_per_s": 2.0 * S * a.tile_rows / mean_kernel_s},
+        }
+        if world == 1 and a.cpu_seconds > 0:
+            out["cpu_baseline"] = cpu_baseline(tb, st, a.seed, a.cpu_seconds)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    gen.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,241 @@
+"""ctypes binding of the C ABI in include/dnaf.h (libdnaf_hip.so).
+
+This is the only way into the generator: there is no CPU fallback.  If the
+HIP library is missing or fails to load, importing this module raises.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
+LIB_PATH = os.environ.get("DNAF_LIB", os.path.join(_CSRC, "libdnaf_hip.so"))
+
+ABI_VERSION = 1
+
+OK = 0
+ERR_BAD_ARG, ERR_HIP, ERR_OOM, ERR_UNSUPPORTED, ERR_STATE, ERR_THRESHOLD = -1, -2, -3, -4, -5, -6
+ERR_NAMES = {-1: "DNAF_ERR_BAD_ARG", -2: "DNAF_ERR_HIP", -3: "DNAF_ERR_OOM", -4: "DNAF_ERR_UNSUPPORTED",
+             -5: "DNAF_ERR_STATE", -6: "DNAF_ERR_THRESHOLD"}
+
+SAMPLE_MALE, SAMPLE_CONTROL = 1, 2
+CLASS_AUTOSOME, CLASS_X, CLASS_Y, CLASS_MT = 0, 1, 2, 3
+MAX_ALLELES = 4
+RNG_PHILOX, RNG_MT19937 = 0, 1
+OUT_TEXT, OUT_PACKED = 1, 2
+
+# every symbol include/dnaf.h declares
+SYMBOLS = [
+    "dnaf_abi_version", "dnaf_device_count", "dnaf_create", "dnaf_destroy", "dnaf_last_error", "dnaf_set_samples",
+    "dnaf_set_forced", "dnaf_set_rng", "dnaf_set_snps", "dnaf_text_bytes", "dnaf_row_offsets", "dnaf_generate",
+    "dnaf_sync", "dnaf_last_generate_ms", "dnaf_timing_begin", "dnaf_timing_end", "dnaf_read_text", "dnaf_read_packed", "dnaf_device_buffers",
+    "dnaf_format_prefixes",
+]
+
+
+class DnafError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__("%s: %s" % (ERR_NAMES.get(code, str(code)), message))
+        self.code = code
+
+
+class SnpTableStruct(ctypes.Structure):
+    """struct dnaf_snp_table"""
+    _fields_ = [
+        ("n_rows", ctypes.c_uint64),
+        ("snp_id", ctypes.c_void_p),
+        ("chrom_class", ctypes.c_void_p),
+        ("n_alleles", ctypes.c_void_p),
+        ("cum_freq", ctypes.c_void_p),
+        ("prefix_bytes", ctypes.c_void_p),
+        ("prefix_off", ctypes.c_void_p),
+    ]
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "HIP library %s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    u64, u32, vp, ci = ctypes.c_uint64, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_int
+    sig = {
+        "dnaf_abi_version": (ci, []),
+        "dnaf_device_count": (ci, [vp]),
+        "dnaf_create": (ci, [ci, vp]),
+        "dnaf_destroy": (ci, [vp]),
+        "dnaf_last_error": (ctypes.c_char_p, [vp]),
+        "dnaf_set_samples": (ci, [vp, vp, u64]),
+        "dnaf_set_forced": (ci, [vp, vp, u64, vp, vp]),
+        "dnaf_set_rng": (ci, [vp, u32, u64, u64]),
+        "dnaf_set_snps": (ci, [vp, vp]),
+        "dnaf_text_bytes": (ci, [vp, u64, u64, vp]),
+        "dnaf_row_offsets": (ci, [vp, u64, u64, vp]),
+        "dnaf_generate": (ci, [vp, u64, u64, u32]),
+        "dnaf_sync": (ci, [vp]),
+        "dnaf_last_generate_ms": (ci, [vp, vp]),
+        "dnaf_timing_begin": (ci, [vp]),
+        "dnaf_timing_end": (ci, [vp, vp, vp, vp]),
+        "dnaf_read_text": (ci, [vp, vp, u64, vp]),
+        "dnaf_read_packed": (ci, [vp, vp, u64, vp]),
+        "dnaf_device_buffers": (ci, [vp, vp, vp, vp, vp]),
+        "dnaf_format_prefixes": (ci, [u64, vp, u32, vp, vp, vp, u32, vp, u32, vp, u64, vp]),
+    }
+    for name in SYMBOLS:
+        fn = getattr(lib, name)  # AttributeError here = the library does not export what the header declares
+        fn.restype, fn.argtypes = sig[name]
+    if lib.dnaf_abi_version() != ABI_VERSION:
+        raise ImportError("%s has ABI version %d, binding expects %d" % (LIB_PATH, lib.dnaf_abi_version(), ABI_VERSION))
+    return lib
+
+
+lib = _load()
+
+
+def ptr(a):
+    return None if a is None else a.ctypes.data_as(ctypes.c_void_p)
+
+
+def device_count():
+    n = ctypes.c_int(0)
+    rc = lib.dnaf_device_count(ctypes.byref(n))
+    if rc != OK:
+        raise DnafError(rc, lib.dnaf_last_error(None).decode())
+    return n.value
+
+
+def format_prefixes(chrom, pos, snp_id, ref, alt):
+    """Fixed columns of each body line (pop_factory.py:503-507) -> (blob u8[], off u64[n+1])."""
+    n = len(pos)
+    chrom = np.ascontiguousarray(chrom)
+    ref = np.ascontiguousarray(ref)
+    alt = np.ascontiguousarray(alt)
+    pos = np.ascontiguousarray(pos, dtype=np.int64)
+    snp_id = np.ascontiguousarray(snp_id, dtype=np.int64)
+    for a in (chrom, ref, alt):
+        if a.dtype.kind != "S" or len(a) != n:
+            raise ValueError("chrom/ref/alt must be numpy bytes ('S<w>') arrays of length n")
+    off = np.zeros(n + 1, dtype=np.uint64)
+    args = (n, ptr(chrom), chrom.dtype.itemsize, ptr(pos), ptr(snp_id), ptr(ref), ref.dtype.itemsize, ptr(alt),
+            alt.dtype.itemsize)
+    rc = lib.dnaf_format_prefixes(*args, None, 0, ptr(off))
+    if rc != OK:
+        raise DnafError(rc, "dnaf_format_prefixes (sizing)")
+    blob = np.empty(max(int(off[n]), 1), dtype=np.uint8)
+    rc = lib.dnaf_format_prefixes(*args, ptr(blob), int(off[n]), ptr(off))
+    if rc != OK:
+        raise DnafError(rc, "dnaf_format_prefixes")
+    return blob[: int(off[n])], off
+
+
+class Context:
+    """One dnaf_ctx: one GPU, one stream.  Not thread-safe."""
+
+    def __init__(self, device=0):
+        self._h = ctypes.c_void_p(None)
+        rc = lib.dnaf_create(int(device), ctypes.byref(self._h))
+        if rc != OK:
+            raise DnafError(rc, lib.dnaf_last_error(None).decode())
+        self.device = int(device)
+
+    def _check(self, rc):
+        if rc != OK:
+            raise DnafError(rc, lib.dnaf_last_error(self._h).decode())
+
+    def close(self):
+        if self._h:
+            lib.dnaf_destroy(self._h)
+            self._h = ctypes.c_void_p(None)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def set_samples(self, flags):
+        flags = np.ascontiguousarray(flags, dtype=np.uint8)
+        self._check(lib.dnaf_set_samples(self._h, ptr(flags), len(flags)))
+
+    def set_forced(self, snp_ids, carrier_off, carrier_idx):
+        snp_ids = np.ascontiguousarray(snp_ids, dtype=np.int64)
+        carrier_off = np.ascontiguousarray(carrier_off, dtype=np.uint64)
+        carrier_idx = np.ascontiguousarray(carrier_idx, dtype=np.uint32)
+        if len(snp_ids) and len(carrier_off) != len(snp_ids) + 1:
+            raise ValueError("carrier_off must have n_slots+1 entries")
+        self._check(lib.dnaf_set_forced(self._h, ptr(snp_ids), len(snp_ids), ptr(carrier_off), ptr(carrier_idx)))
+
+    def set_rng(self, mode, seed, rng_row0=0):
+        self._check(lib.dnaf_set_rng(self._h, mode, int(seed) & 0xFFFFFFFFFFFFFFFF, int(rng_row0)))
+
+    def set_snps(self, snp_id, chrom_class, n_alleles, cum_freq, prefix_bytes, prefix_off):
+        n = len(snp_id)
+        snp_id = np.ascontiguousarray(snp_id, dtype=np.int64)
+        chrom_class = np.ascontiguousarray(chrom_class, dtype=np.uint8)
+        n_alleles = np.ascontiguousarray(n_alleles, dtype=np.uint8)
+        cum_freq = np.ascontiguousarray(cum_freq, dtype=np.float64)
+        prefix_bytes = np.ascontiguousarray(prefix_bytes, dtype=np.uint8)
+        prefix_off = np.ascontiguousarray(prefix_off, dtype=np.uint64)
+        if cum_freq.shape != (n, MAX_ALLELES) or len(chrom_class) != n or len(n_alleles) != n or len(prefix_off) != n + 1:
+            raise ValueError("SNP table columns have inconsistent shapes")
+        if n and int(prefix_off[n]) > len(prefix_bytes):
+            raise ValueError("prefix_off runs past prefix_bytes")
+        t = SnpTableStruct(n, ptr(snp_id).value, ptr(chrom_class).value, ptr(n_alleles).value, ptr(cum_freq).value,
+                           ptr(prefix_bytes).value if len(prefix_bytes) else None, ptr(prefix_off).value)
+        self._check(lib.dnaf_set_snps(self._h, ctypes.byref(t)))
+
+    def text_bytes(self, row_begin, n_rows):
+        v = ctypes.c_uint64(0)
+        self._check(lib.dnaf_text_bytes(self._h, row_begin, n_rows, ctypes.byref(v)))
+        return v.value
+
+    def row_offsets(self, row_begin, n_rows):
+        off = np.zeros(n_rows + 1, dtype=np.uint64)
+        self._check(lib.dnaf_row_offsets(self._h, row_begin, n_rows, ptr(off)))
+        return off
+
+    def generate(self, row_begin, n_rows, what=OUT_TEXT | OUT_PACKED):
+        self._check(lib.dnaf_generate(self._h, row_begin, n_rows, what))
+
+    def sync(self):
+        self._check(lib.dnaf_sync(self._h))
+
+    def last_generate_ms(self):
+        v = ctypes.c_float(0)
+        self._check(lib.dnaf_last_generate_ms(self._h, ctypes.byref(v)))
+        return v.value
+
+    def timing_begin(self):
+        self._check(lib.dnaf_timing_begin(self._h))
+
+    def timing_end(self):
+        """-> (summed kernel ms, launches recorded, launches made)"""
+        tot = ctypes.c_double(0)
+        nr, nl = ctypes.c_uint64(0), ctypes.c_uint64(0)
+        self._check(lib.dnaf_timing_end(self._h, ctypes.byref(tot), ctypes.byref(nr), ctypes.byref(nl)))
+        return tot.value, nr.value, nl.value
+
+    def read_text(self, n_bytes):
+        buf = np.empty(max(n_bytes, 1), dtype=np.uint8)
+        got = ctypes.c_uint64(0)
+        self._check(lib.dnaf_read_text(self._h, ptr(buf), n_bytes, ctypes.byref(got)))
+        return buf[: got.value]
+
+    def read_packed(self, n_rows, words_per_row):
+        buf = np.empty((n_rows, words_per_row), dtype=np.uint32)
+        got = ctypes.c_uint64(0)
+        flat = buf.reshape(-1) if buf.size else np.empty(1, dtype=np.uint32)
+        self._check(lib.dnaf_read_packed(self._h, ptr(flat), buf.size, ctypes.byref(got)))
+        return buf
+
+    def device_buffers(self):
+        t, p = ctypes.c_void_p(None), ctypes.c_void_p(None)
+        tb, pw = ctypes.c_uint64(0), ctypes.c_uint64(0)
+        self._check(lib.dnaf_device_buffers(self._h, ctypes.byref(t), ctypes.byref(tb), ctypes.byref(p), ctypes.byref(pw)))
+        return t.value, tb.value, p.value, pw.value

@@ -1,0 +1,558 @@
+// dnaf_api.hip -- C ABI (include/dnaf.h) over the gfx950 row-generation kernels.
+//
+// Host responsibilities, all one-shot per table: integer thresholds from the
+// float64 cumulative frequencies, forced-set slots, text layout (row offsets
+// by prefix sum), sample nibble tables.  dnaf_generate() itself only
+// launches the kernel on the context's stream.
+#include "../../include/dnaf.h"
+#include "rowgen_kernels.hip.h"
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+using dnaf::GenParams;
+using dnaf::RowRec;
+
+struct dnaf_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::vector<hipEvent_t> evs; // event pairs, one per kernel launch since dnaf_timing_begin
+    size_t n_timed = 0;          // launches recorded
+    uint64_t n_launches = 0;     // launches since dnaf_timing_begin (recorded or not)
+    std::string err;
+
+    // samples
+    bool have_samples = false;
+    uint32_t S = 0, G = 0, W = 0, n_male = 0;
+    uint64_t x_row_bytes = 0; // cells of an X row
+    uint8_t* d_male_nib = nullptr;
+    uint32_t* d_xoff = nullptr;
+    std::vector<uint8_t> h_flags;
+
+    // forced set
+    uint64_t n_slots = 0;
+    uint8_t* d_forced = nullptr;
+    std::unordered_map<int64_t, int32_t> slot_of;
+
+    // rng
+    uint32_t rng_mode = DNAF_RNG_PHILOX;
+    uint64_t seed = 0, rng_row0 = 0;
+
+    // snp table
+    bool have_snps = false;
+    uint64_t n_rows = 0;
+    RowRec* d_recs = nullptr;
+    uint8_t* d_prefix = nullptr;
+    std::vector<uint64_t> h_text_off; // [n_rows+1]
+
+    // outputs
+    uint8_t* d_text = nullptr;
+    uint64_t text_cap = 0;
+    uint8_t* d_packed = nullptr;
+    uint64_t packed_cap = 0;
+    uint64_t last_begin = 0, last_rows = 0;
+    uint32_t last_what = 0;
+    bool have_output = false;
+
+    // tuning
+    uint32_t seg_iters = 32;
+};
+
+static const size_t MAX_TIMED = 4096;
+static thread_local std::string g_create_err = "";
+
+static int fail(dnaf_ctx* c, int code, const char* fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (c) c->err = buf;
+    else g_create_err = buf;
+    return code;
+}
+
+#define HIP_TRY(c, expr)                                                                                     \
+    do {                                                                                                     \
+        hipError_t e_ = (expr);                                                                              \
+        if (e_ != hipSuccess)                                                                                \
+            return fail((c), e_ == hipErrorOutOfMemory ? DNAF_ERR_OOM : DNAF_ERR_HIP, "%s: %s", #expr,       \
+                        hipGetErrorString(e_));                                                              \
+    } while (0)
+
+template <class T>
+static void dev_free(T*& p)
+{
+    if (p) (void)hipFree(p);
+    p = nullptr;
+}
+
+extern "C" {
+
+int dnaf_abi_version(void) { return DNAF_ABI_VERSION; }
+
+int dnaf_device_count(int* count)
+{
+    if (!count) return DNAF_ERR_BAD_ARG;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        *count = 0;
+        return fail(nullptr, DNAF_ERR_HIP, "hipGetDeviceCount: %s", hipGetErrorString(e));
+    }
+    *count = n;
+    return DNAF_OK;
+}
+
+int dnaf_create(int device, dnaf_ctx** out)
+{
+    if (!out) return fail(nullptr, DNAF_ERR_BAD_ARG, "dnaf_create: out is NULL");
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return fail(nullptr, DNAF_ERR_HIP, "dnaf_create: no HIP device (%s)", hipGetErrorString(e));
+    if (device < 0 || device >= n) return fail(nullptr, DNAF_ERR_BAD_ARG, "dnaf_create: device %d of %d", device, n);
+    dnaf_ctx* c = new (std::nothrow) dnaf_ctx();
+    if (!c) return fail(nullptr, DNAF_ERR_OOM, "dnaf_create: host allocation");
+    c->device = device;
+    if ((e = hipSetDevice(device)) != hipSuccess || (e = hipStreamCreate(&c->stream)) != hipSuccess) {
+        delete c;
+        return fail(nullptr, DNAF_ERR_HIP, "dnaf_create: %s", hipGetErrorString(e));
+    }
+    if (const char* s = getenv("DNAF_SEG_ITERS")) {
+        int v = atoi(s);
+        if (v >= 1 && v <= 4096) c->seg_iters = (uint32_t)v;
+    }
+    *out = c;
+    return DNAF_OK;
+}
+
+int dnaf_destroy(dnaf_ctx* c)
+{
+    if (!c) return DNAF_OK;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    dev_free(c->d_male_nib);
+    dev_free(c->d_xoff);
+    dev_free(c->d_forced);
+    dev_free(c->d_recs);
+    dev_free(c->d_prefix);
+    dev_free(c->d_text);
+    dev_free(c->d_packed);
+    for (hipEvent_t e : c->evs) (void)hipEventDestroy(e);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+    return DNAF_OK;
+}
+
+const char* dnaf_last_error(const dnaf_ctx* c) { return c ? c->err.c_str() : g_create_err.c_str(); }
+
+int dnaf_set_samples(dnaf_ctx* c, const uint8_t* flags, uint64_t n_samples)
+{
+    if (!c) return DNAF_ERR_BAD_ARG;
+    if (n_samples && !flags) return fail(c, DNAF_ERR_BAD_ARG, "dnaf_set_samples: flags is NULL");
+    if (n_samples > 0x3FFFFFFFull) return fail(c, DNAF_ERR_UNSUPPORTED, "dnaf_set_samples: more than 2^30-1 samples");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->have_samples = c->have_snps = c->have_output = false;
+    c->n_slots = 0;
+    c->slot_of.clear();
+    dev_free(c->d_forced);
+    dev_free(c->d_male_nib);
+    dev_free(c->d_xoff);
+    c->S = (uint32_t)n_samples;
+    c->G = (c->S + 3u) / 4u;
+    c->W = (c->S + 15u) / 16u;
+    c->h_flags.assign(flags, flags + n_samples);
+    std::vector<uint8_t> nib(c->G ? c->G : 1, 0);
+    std::vector<uint32_t> xoff((size_t)c->G + 1, 0);
+    uint32_t n_male = 0;
+    uint64_t off = 0;
+    for (uint32_t i = 0; i < c->S; ++i) {
+        if ((i & 3u) == 0) xoff[i >> 2] = (uint32_t)off;
+        const bool male = flags[i] & DNAF_SAMPLE_MALE;
+        if (male) { nib[i >> 2] |= (uint8_t)(1u << (i & 3u)); ++n_male; }
+        off += male ? 2 : 4;
+        if (off > 0xFFFFFFF0ull) return fail(c, DNAF_ERR_UNSUPPORTED, "dnaf_set_samples: row longer than 4 GiB");
+    }
+    xoff[c->G] = (uint32_t)off;
+    c->n_male = n_male;
+    c->x_row_bytes = off;
+    HIP_TRY(c, hipMalloc((void**)&c->d_male_nib, nib.size()));
+    HIP_TRY(c, hipMalloc((void**)&c->d_xoff, xoff.size() * sizeof(uint32_t)));
+    HIP_TRY(c, hipMemcpy(c->d_male_nib, nib.data(), nib.size(), hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpy(c->d_xoff, xoff.data(), xoff.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    c->have_samples = true;
+    return DNAF_OK;
+}
+
+int dnaf_set_forced(dnaf_ctx* c, const int64_t* snp_ids, uint64_t n_slots, const uint64_t* carrier_off,
+                    const uint32_t* carrier_idx)
+{
+    if (!c) return DNAF_ERR_BAD_ARG;
+    if (!c->have_samples) return fail(c, DNAF_ERR_STATE, "dnaf_set_forced: call dnaf_set_samples first");
+    if (n_slots && (!snp_ids || !carrier_off)) return fail(c, DNAF_ERR_BAD_ARG, "dnaf_set_forced: NULL argument");
+    if (n_slots > 0x7FFFFFFFull) return fail(c, DNAF_ERR_UNSUPPORTED, "dnaf_set_forced: too many slots");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->have_snps = c->have_output = false; // rows' slots are resolved in dnaf_set_snps
+    c->n_slots = 0;
+    c->slot_of.clear();
+    dev_free(c->d_forced);
+    if (n_slots == 0) return DNAF_OK;
+    const uint64_t G = c->G ? c->G : 1;
+    std::vector<uint8_t> nib;
+    try {
+        nib.assign((size_t)(n_slots * G), 0);
+    } catch (const std::bad_alloc&) {
+        return fail(c, DNAF_ERR_OOM, "dnaf_set_forced: host allocation of %llu bytes", (unsigned long long)(n_slots * G));
+    }
+    for (uint64_t k = 0; k < n_slots; ++k) {
+        if (carrier_off[k + 1] < carrier_off[k]) return fail(c, DNAF_ERR_BAD_ARG, "dnaf_set_forced: carrier_off not monotone");
+        if (c->slot_of.count(snp_ids[k])) return fail(c, DNAF_ERR_BAD_ARG, "dnaf_set_forced: duplicate snp id %lld", (long long)snp_ids[k]);
+        c->slot_of[snp_ids[k]] = (int32_t)k;
+        for (uint64_t j = carrier_off[k]; j < carrier_off[k + 1]; ++j) {
+            const uint32_t i = carrier_idx[j];
+            if (i >= c->S) return fail(c, DNAF_ERR_BAD_ARG, "dnaf_set_forced: sample index %u out of range", i);
+            if (c->h_flags[i] & DNAF_SAMPLE_CONTROL)
+                return fail(c, DNAF_ERR_BAD_ARG, "dnaf_set_forced: sample %u is a control (never forced, pop_factory.py:485)", i);
+            nib[(size_t)(k * G + (i >> 2))] |= (uint8_t)(1u << (i & 3u));
+        }
+    }
+    HIP_TRY(c, hipMalloc((void**)&c->d_forced, nib.size()));
+    HIP_TRY(c, hipMemcpy(c->d_forced, nib.data(), nib.size(), hipMemcpyHostToDevice));
+    c->n_slots = n_slots;
+    return DNAF_OK;
+}
+
+int dnaf_set_rng(dnaf_ctx* c, uint32_t mode, uint64_t seed, uint64_t rng_row0)
+{
+    if (!c) return DNAF_ERR_BAD_ARG;
+    if (mode == DNAF_RNG_MT19937)
+        return fail(c, DNAF_ERR_UNSUPPORTED, "dnaf_set_rng: DNAF_RNG_MT19937 is not implemented in this build");
+    if (mode != DNAF_RNG_PHILOX) return fail(c, DNAF_ERR_BAD_ARG, "dnaf_set_rng: unknown mode %u", mode);
+    c->rng_mode = mode;
+    c->seed = seed;
+    c->rng_row0 = rng_row0;
+    return DNAF_OK;
+}
+
+// floor(cum * 2^32) clamped to u32: `cum >= u * 2^-32` <=> u <= T (both sides exact in float64)
+static bool threshold_u32(double cum, uint32_t* t)
+{
+    if (!(cum >= 0.0)) return false; // negative or NaN
+    const double s = std::floor(cum * 4294967296.0);
+    *t = s >= 4294967295.0 ? 0xFFFFFFFFu : (uint32_t)s;
+    return true;
+}
+
+int dnaf_set_snps(dnaf_ctx* c, const dnaf_snp_table* t)
+{
+    if (!c) return DNAF_ERR_BAD_ARG;
+    if (!c->have_samples) return fail(c, DNAF_ERR_STATE, "dnaf_set_snps: call dnaf_set_samples first");
+    if (!t) return fail(c, DNAF_ERR_BAD_ARG, "dnaf_set_snps: table is NULL");
+    const uint64_t n = t->n_rows;
+    if (n && (!t->snp_id || !t->chrom_class || !t->n_alleles || !t->cum_freq || !t->prefix_off))
+        return fail(c, DNAF_ERR_BAD_ARG, "dnaf_set_snps: NULL column");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->have_snps = c->have_output = false;
+    dev_free(c->d_recs);
+    dev_free(c->d_prefix);
+    std::vector<RowRec> recs;
+    try {
+        recs.resize((size_t)n);
+        c->h_text_off.assign((size_t)n + 1, 0);
+    } catch (const std::bad_alloc&) {
+        return fail(c, DNAF_ERR_OOM, "dnaf_set_snps: host allocation for %llu rows", (unsigned long long)n);
+    }
+    const uint64_t S = c->S;
+    const uint64_t cells_len[4] = {S ? 4 * S : 1, S ? c->x_row_bytes : 1, S ? 2 * S : 1, S ? 2 * S : 1};
+    const uint64_t pbase = n ? t->prefix_off[0] : 0;
+    uint64_t off = 0;
+    for (uint64_t j = 0; j < n; ++j) {
+        RowRec& r = recs[(size_t)j];
+        const uint32_t na = t->n_alleles[j], cls = t->chrom_class[j];
+        if (na < 1 || na > DNAF_MAX_ALLELES)
+            return fail(c, DNAF_ERR_UNSUPPORTED, "dnaf_set_snps: row %llu has %u alleles (1..%d supported)", (unsigned long long)j, na, DNAF_MAX_ALLELES);
+        if (cls > DNAF_CLASS_MT) return fail(c, DNAF_ERR_BAD_ARG, "dnaf_set_snps: row %llu chrom_class %u", (unsigned long long)j, cls);
+        uint32_t thr[DNAF_MAX_ALLELES] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+        for (uint32_t k = 0; k < na; ++k)
+            if (!threshold_u32(t->cum_freq[j * DNAF_MAX_ALLELES + k], &thr[k]))
+                return fail(c, DNAF_ERR_BAD_ARG, "dnaf_set_snps: row %llu cumulative frequency %u is negative or NaN", (unsigned long long)j, k);
+        if (S && thr[na - 1] != 0xFFFFFFFFu)
+            return fail(c, DNAF_ERR_THRESHOLD, "dnaf_set_snps: row %llu last cumulative frequency %.17g < 1: a roll above it has no allele "
+                        "(the reference raises TypeError, pop_factory.py:489)", (unsigned long long)j, t->cum_freq[j * DNAF_MAX_ALLELES + na - 1]);
+        r.thr[0] = thr[0]; r.thr[1] = thr[1]; r.thr[2] = thr[2];
+        if (t->prefix_off[j + 1] < t->prefix_off[j]) return fail(c, DNAF_ERR_BAD_ARG, "dnaf_set_snps: prefix_off not monotone at row %llu", (unsigned long long)j);
+        const uint64_t plen = t->prefix_off[j + 1] - t->prefix_off[j], poff = t->prefix_off[j] - pbase;
+        if (plen > 0xFFFFu || poff > 0xFFFFFFFFull)
+            return fail(c, DNAF_ERR_UNSUPPORTED, "dnaf_set_snps: row %llu prefix too long / prefix blob over 4 GiB", (unsigned long long)j);
+        r.prefix_off = (uint32_t)poff;
+        r.prefix_len = (uint16_t)plen;
+        r.text_off = off;
+        auto it = c->n_slots ? c->slot_of.find(t->snp_id[j]) : c->slot_of.end();
+        r.slot = it == c->slot_of.end() ? -1 : it->second;
+        r.cls = (uint8_t)cls;
+        r.n_alleles = (uint8_t)na;
+        c->h_text_off[(size_t)j] = off;
+        off += plen + cells_len[cls];
+    }
+    c->h_text_off[(size_t)n] = off;
+    const uint64_t pbytes = n ? t->prefix_off[n] - pbase : 0;
+    if (pbytes && !t->prefix_bytes) return fail(c, DNAF_ERR_BAD_ARG, "dnaf_set_snps: prefix_bytes is NULL");
+    HIP_TRY(c, hipMalloc((void**)&c->d_recs, (n ? n : 1) * sizeof(RowRec)));
+    HIP_TRY(c, hipMalloc((void**)&c->d_prefix, pbytes ? pbytes : 1));
+    if (n) HIP_TRY(c, hipMemcpy(c->d_recs, recs.data(), n * sizeof(RowRec), hipMemcpyHostToDevice));
+    if (pbytes) HIP_TRY(c, hipMemcpy(c->d_prefix, t->prefix_bytes + pbase, pbytes, hipMemcpyHostToDevice));
+    c->n_rows = n;
+    c->have_snps = true;
+    return DNAF_OK;
+}
+
+static int check_range(const dnaf_ctx* c, uint64_t b, uint64_t n)
+{
+    if (!c || !c->have_snps) return DNAF_ERR_STATE;
+    if (b > c->n_rows || n > c->n_rows - b) return DNAF_ERR_BAD_ARG;
+    return DNAF_OK;
+}
+
+int dnaf_text_bytes(const dnaf_ctx* c, uint64_t row_begin, uint64_t n_rows, uint64_t* bytes)
+{
+    if (!c || !bytes) return DNAF_ERR_BAD_ARG;
+    if (int rc = check_range(c, row_begin, n_rows))
+        return fail(const_cast<dnaf_ctx*>(c), rc, "dnaf_text_bytes: no SNP table or rows [%llu,+%llu) out of range", (unsigned long long)row_begin, (unsigned long long)n_rows);
+    *bytes = c->h_text_off[(size_t)(row_begin + n_rows)] - c->h_text_off[(size_t)row_begin];
+    return DNAF_OK;
+}
+
+int dnaf_row_offsets(const dnaf_ctx* c, uint64_t row_begin, uint64_t n_rows, uint64_t* off)
+{
+    if (!c || !off) return DNAF_ERR_BAD_ARG;
+    if (int rc = check_range(c, row_begin, n_rows))
+        return fail(const_cast<dnaf_ctx*>(c), rc, "dnaf_row_offsets: no SNP table or rows [%llu,+%llu) out of range", (unsigned long long)row_begin, (unsigned long long)n_rows);
+    const uint64_t base = c->h_text_off[(size_t)row_begin];
+    for (uint64_t j = 0; j <= n_rows; ++j) off[j] = c->h_text_off[(size_t)(row_begin + j)] - base;
+    return DNAF_OK;
+}
+
+int dnaf_generate(dnaf_ctx* c, uint64_t row_begin, uint64_t n_rows, uint32_t what)
+{
+    if (!c) return DNAF_ERR_BAD_ARG;
+    if (int rc = check_range(c, row_begin, n_rows))
+        return fail(c, rc, "dnaf_generate: no SNP table or rows [%llu,+%llu) out of range", (unsigned long long)row_begin, (unsigned long long)n_rows);
+    if (!(what & (DNAF_OUT_TEXT | DNAF_OUT_PACKED)) || (what & ~(DNAF_OUT_TEXT | DNAF_OUT_PACKED)))
+        return fail(c, DNAF_ERR_BAD_ARG, "dnaf_generate: what = %u", what);
+    HIP_TRY(c, hipSetDevice(c->device));
+    const uint64_t tbytes = c->h_text_off[(size_t)(row_begin + n_rows)] - c->h_text_off[(size_t)row_begin];
+    const uint64_t pbytes = n_rows * (uint64_t)c->W * 4u;
+    if ((what & DNAF_OUT_TEXT) && tbytes > c->text_cap) {
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        dev_free(c->d_text);
+        c->text_cap = 0;
+        HIP_TRY(c, hipMalloc((void**)&c->d_text, tbytes + 64)); // slack: nothing is stored past tbytes
+        c->text_cap = tbytes;
+    }
+    if ((what & DNAF_OUT_PACKED) && pbytes > c->packed_cap) {
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        dev_free(c->d_packed);
+        c->packed_cap = 0;
+        HIP_TRY(c, hipMalloc((void**)&c->d_packed, pbytes + 64));
+        c->packed_cap = pbytes;
+    }
+    c->last_begin = row_begin;
+    c->last_rows = n_rows;
+    c->last_what = what;
+    c->have_output = true;
+    if (n_rows == 0) return DNAF_OK;
+
+    GenParams p;
+    p.recs = c->d_recs;
+    p.prefix = c->d_prefix;
+    p.male_nib = c->d_male_nib;
+    p.xoff = c->d_xoff;
+    p.forced = c->d_forced;
+    p.text = c->d_text;
+    p.packed = c->d_packed;
+    p.text_base = c->h_text_off[(size_t)row_begin];
+    p.row_begin = row_begin;
+    p.n_rows = n_rows;
+    p.rng_row0 = c->rng_row0;
+    p.key0 = (uint32_t)c->seed;
+    p.key1 = (uint32_t)(c->seed >> 32);
+    p.S = c->S; p.G = c->G; p.W = c->W;
+    p.seg_groups = 64u * c->seg_iters;
+    p.nseg = c->G ? (c->G + p.seg_groups - 1) / p.seg_groups : 1;
+    const uint64_t items = n_rows * p.nseg;
+    const uint64_t blocks = (items + 3) / 4;
+    if (blocks > 0x7FFFFFFFull) return fail(c, DNAF_ERR_UNSUPPORTED, "dnaf_generate: %llu workgroups; generate fewer rows per call", (unsigned long long)blocks);
+    // one event pair per launch, on the launch stream (pool bounded: later launches go unrecorded)
+    const bool rec = c->n_timed < MAX_TIMED;
+    if (rec && c->evs.size() < 2 * (c->n_timed + 1)) {
+        hipEvent_t a = nullptr, b = nullptr;
+        HIP_TRY(c, hipEventCreate(&a));
+        c->evs.push_back(a);
+        HIP_TRY(c, hipEventCreate(&b));
+        c->evs.push_back(b);
+    }
+    if (rec) HIP_TRY(c, hipEventRecord(c->evs[2 * c->n_timed], c->stream));
+    const dim3 grid((uint32_t)blocks), block(256);
+    if (what == (DNAF_OUT_TEXT | DNAF_OUT_PACKED)) hipLaunchKernelGGL((dnaf::rowgen_kernel<true, true>), grid, block, 0, c->stream, p);
+    else if (what == DNAF_OUT_TEXT) hipLaunchKernelGGL((dnaf::rowgen_kernel<true, false>), grid, block, 0, c->stream, p);
+    else hipLaunchKernelGGL((dnaf::rowgen_kernel<false, true>), grid, block, 0, c->stream, p);
+    HIP_TRY(c, hipGetLastError());
+    if (rec) {
+        HIP_TRY(c, hipEventRecord(c->evs[2 * c->n_timed + 1], c->stream));
+        ++c->n_timed;
+    }
+    ++c->n_launches;
+    return DNAF_OK;
+}
+
+int dnaf_sync(dnaf_ctx* c)
+{
+    if (!c) return DNAF_ERR_BAD_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return DNAF_OK;
+}
+
+int dnaf_last_generate_ms(dnaf_ctx* c, float* ms)
+{
+    if (!c || !ms) return DNAF_ERR_BAD_ARG;
+    *ms = 0.f;
+    if (!c->n_timed) return fail(c, DNAF_ERR_STATE, "dnaf_last_generate_ms: no kernel launch was recorded");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipEventSynchronize(c->evs[2 * c->n_timed - 1]));
+    HIP_TRY(c, hipEventElapsedTime(ms, c->evs[2 * c->n_timed - 2], c->evs[2 * c->n_timed - 1]));
+    return DNAF_OK;
+}
+
+int dnaf_timing_begin(dnaf_ctx* c)
+{
+    if (!c) return DNAF_ERR_BAD_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->n_timed = 0;
+    c->n_launches = 0;
+    return DNAF_OK;
+}
+
+int dnaf_timing_end(dnaf_ctx* c, double* total_ms, uint64_t* n_recorded, uint64_t* n_launches)
+{
+    if (!c || !total_ms) return DNAF_ERR_BAD_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    double tot = 0.0;
+    for (size_t i = 0; i < c->n_timed; ++i) {
+        float ms = 0.f;
+        HIP_TRY(c, hipEventElapsedTime(&ms, c->evs[2 * i], c->evs[2 * i + 1]));
+        tot += ms;
+    }
+    *total_ms = tot;
+    if (n_recorded) *n_recorded = c->n_timed;
+    if (n_launches) *n_launches = c->n_launches;
+    return DNAF_OK;
+}
+
+int dnaf_read_text(dnaf_ctx* c, void* dst, uint64_t dst_cap, uint64_t* n_bytes)
+{
+    if (!c) return DNAF_ERR_BAD_ARG;
+    if (!c->have_output || !(c->last_what & DNAF_OUT_TEXT)) return fail(c, DNAF_ERR_STATE, "dnaf_read_text: no text was generated");
+    const uint64_t n = c->h_text_off[(size_t)(c->last_begin + c->last_rows)] - c->h_text_off[(size_t)c->last_begin];
+    if (n_bytes) *n_bytes = n;
+    if (n > dst_cap) return fail(c, DNAF_ERR_BAD_ARG, "dnaf_read_text: need %llu bytes, have %llu", (unsigned long long)n, (unsigned long long)dst_cap);
+    if (n && !dst) return fail(c, DNAF_ERR_BAD_ARG, "dnaf_read_text: dst is NULL");
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (n) HIP_TRY(c, hipMemcpyAsync(dst, c->d_text, n, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return DNAF_OK;
+}
+
+int dnaf_read_packed(dnaf_ctx* c, uint32_t* dst, uint64_t dst_cap_words, uint64_t* n_words)
+{
+    if (!c) return DNAF_ERR_BAD_ARG;
+    if (!c->have_output || !(c->last_what & DNAF_OUT_PACKED)) return fail(c, DNAF_ERR_STATE, "dnaf_read_packed: no packed matrix was generated");
+    const uint64_t n = c->last_rows * (uint64_t)c->W;
+    if (n_words) *n_words = n;
+    if (n > dst_cap_words) return fail(c, DNAF_ERR_BAD_ARG, "dnaf_read_packed: need %llu words, have %llu", (unsigned long long)n, (unsigned long long)dst_cap_words);
+    if (n && !dst) return fail(c, DNAF_ERR_BAD_ARG, "dnaf_read_packed: dst is NULL");
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (n) HIP_TRY(c, hipMemcpyAsync(dst, c->d_packed, n * 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return DNAF_OK;
+}
+
+int dnaf_device_buffers(dnaf_ctx* c, void** d_text, uint64_t* text_bytes, void** d_packed, uint64_t* packed_words)
+{
+    if (!c) return DNAF_ERR_BAD_ARG;
+    if (!c->have_output) return fail(c, DNAF_ERR_STATE, "dnaf_device_buffers: nothing was generated");
+    const bool t = c->last_what & DNAF_OUT_TEXT, k = c->last_what & DNAF_OUT_PACKED;
+    if (d_text) *d_text = t ? c->d_text : nullptr;
+    if (text_bytes) *text_bytes = t ? c->h_text_off[(size_t)(c->last_begin + c->last_rows)] - c->h_text_off[(size_t)c->last_begin] : 0;
+    if (d_packed) *d_packed = k ? c->d_packed : nullptr;
+    if (packed_words) *packed_words = k ? c->last_rows * (uint64_t)c->W : 0;
+    return DNAF_OK;
+}
+
+// ---- host helper: fixed columns of a VCF body line, pop_factory.py:503-507 ----
+static inline size_t put_i64(uint8_t* p, int64_t v)
+{
+    char tmp[24];
+    size_t n = 0;
+    uint64_t u = v < 0 ? (uint64_t)0 - (uint64_t)v : (uint64_t)v;
+    do { tmp[n++] = (char)('0' + u % 10); u /= 10; } while (u);
+    size_t k = 0;
+    if (v < 0) p[k++] = '-';
+    while (n) p[k++] = (uint8_t)tmp[--n];
+    return k;
+}
+static inline size_t field_len(const char* f, uint32_t w)
+{
+    size_t n = 0;
+    while (n < w && f[n]) ++n;
+    return n;
+}
+
+int dnaf_format_prefixes(uint64_t n, const char* chrom, uint32_t chrom_w, const int64_t* pos, const int64_t* id,
+                         const char* ref, uint32_t ref_w, const char* alt, uint32_t alt_w, uint8_t* out,
+                         uint64_t out_cap, uint64_t* off)
+{
+    if (!off || (n && (!chrom || !pos || !id || !ref || !alt))) return DNAF_ERR_BAD_ARG;
+    static const char tail[] = "\t40\tPASS\t.\tGT\t";
+    const size_t tail_n = sizeof tail - 1;
+    uint64_t o = 0;
+    uint8_t scratch[64];
+    for (uint64_t j = 0; j < n; ++j) {
+        const char *c = chrom + j * chrom_w, *r = ref + j * ref_w, *a = alt + j * alt_w;
+        const size_t cl = field_len(c, chrom_w), rl = field_len(r, ref_w), al = field_len(a, alt_w);
+        off[j] = o;
+        const size_t pl = put_i64(scratch, pos[j]), il = put_i64(scratch + 24, id[j]);
+        const uint64_t need = cl + 1 + pl + 1 + 2 + il + 1 + rl + 1 + al + tail_n;
+        if (out) {
+            if (o + need > out_cap) return DNAF_ERR_BAD_ARG;
+            uint8_t* p = out + o;
+            memcpy(p, c, cl); p += cl; *p++ = '\t';
+            memcpy(p, scratch, pl); p += pl; *p++ = '\t';
+            *p++ = 'r'; *p++ = 's';
+            memcpy(p, scratch + 24, il); p += il; *p++ = '\t';
+            memcpy(p, r, rl); p += rl; *p++ = '\t';
+            memcpy(p, a, al); p += al;
+            memcpy(p, tail, tail_n);
+        }
+        o += need;
+    }
+    off[n] = o;
+    return DNAF_OK;
+}
+
+} // extern "C"

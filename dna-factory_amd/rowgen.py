@@ -1,0 +1,101 @@
+"""Host-side mirror of the reference's worker/dispatcher seam on top of the C ABI.
+
+`RowGenerator.write_vcf_snps(fam_data, snps, file)` has the meaning of
+`PopulationFactory.write_vcf_snps` (pop_factory.py:417-469): append exactly
+len(snps) VCF body lines to `file`, in order.  The rows are produced by the
+gfx950 kernels (the work of `queue_vcf_snps`, pop_factory.py:471-513); the
+stripe/fork/merge machinery of the reference has no counterpart because a
+counter-based RNG makes every row independent of the partition.
+"""
+import io
+
+import numpy as np
+
+from . import capi
+from .tables import SampleTable, SnpTable
+
+RNG_MODES = {"philox": capi.RNG_PHILOX, "mt19937": capi.RNG_MT19937}
+
+
+class RowGenerator:
+    def __init__(self, device=0, seed=0, rng="philox"):
+        if rng not in RNG_MODES:
+            raise ValueError("rng must be one of %s" % sorted(RNG_MODES))
+        self.ctx = capi.Context(device)
+        self.seed = int(seed)
+        self.rng = rng
+        self.ctx.set_rng(RNG_MODES[rng], self.seed, 0)
+        self.n_samples = None
+        self.n_rows = None
+
+    def close(self):
+        self.ctx.close()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    # ---- inputs -------------------------------------------------------------
+    def set_samples(self, samples):
+        """samples: SampleTable or an iterable accepted by SampleTable.from_samples (the worker's fam_data)."""
+        st = samples if isinstance(samples, SampleTable) else SampleTable.from_samples(samples)
+        self.ctx.set_samples(st.flags)
+        self.ctx.set_forced(st.forced_ids, st.carrier_off, st.carrier_idx)
+        self.n_samples = len(st)
+        self.n_rows = None
+        return st
+
+    def set_snps(self, snps, rng_row0=0):
+        """snps: SnpTable or an iterable accepted by SnpTable.from_snps (the worker's work_q, in output order).
+        rng_row0: RNG row index of the first row (global row index of a shard)."""
+        if self.n_samples is None:
+            raise capi.DnafError(capi.ERR_STATE, "set_samples must be called before set_snps")
+        tb = snps if isinstance(snps, SnpTable) else SnpTable.from_snps(snps)
+        blob, off = tb.prefixes()
+        self.ctx.set_rng(RNG_MODES[self.rng], self.seed, rng_row0)
+        self.ctx.set_snps(tb.snp_id, tb.chrom_class, tb.n_alleles, tb.cum, blob, off)
+        self.n_rows = len(tb)
+        return tb
+
+    # ---- generation ---------------------------------------------------------
+    @property
+    def words_per_row(self):
+        return (self.n_samples + 15) // 16
+
+    def generate(self, row_begin=0, n_rows=None, text=True, packed=True):
+        """Rows [row_begin, row_begin+n_rows) -> (text u8[] or None, row_off u64[n+1], packed u32[n][W] or None)."""
+        if self.n_rows is None:
+            raise capi.DnafError(capi.ERR_STATE, "set_snps must be called before generate")
+        if n_rows is None:
+            n_rows = self.n_rows - row_begin
+        what = (capi.OUT_TEXT if text else 0) | (capi.OUT_PACKED if packed else 0)
+        self.ctx.generate(row_begin, n_rows, what)
+        off = self.ctx.row_offsets(row_begin, n_rows)
+        t = self.ctx.read_text(int(off[n_rows])) if text else None
+        p = self.ctx.read_packed(n_rows, self.words_per_row) if packed else None
+        return t, off, p
+
+    def lines(self, row_begin=0, n_rows=None):
+        t, off, _ = self.generate(row_begin, n_rows, text=True, packed=False)
+        b = t.tobytes()
+        return [b[int(off[j]): int(off[j + 1])].decode("ascii") for j in range(len(off) - 1)]
+
+    def write_vcf_snps(self, fam_data, snps, file, tile_rows=None, rng_row0=0):
+        """Drop-in for PopulationFactory.write_vcf_snps (pop_factory.py:417-418): appends len(snps) lines
+        to `file` (text- or binary-mode, anything with .write) in order.  Returns the number of lines."""
+        self.set_samples(fam_data)
+        tb = self.set_snps(snps, rng_row0=rng_row0)
+        n = len(tb)
+        if tile_rows is None:
+            # keep a tile's text near 256 MiB
+            per_row = 64 + 4 * max(self.n_samples, 1)
+            tile_rows = max(1, min(n, (256 << 20) // per_row)) if n else 1
+        as_text = isinstance(file, io.TextIOBase)
+        for b in range(0, n, tile_rows):
+            m = min(tile_rows, n - b)
+            t, _, _ = self.generate(b, m, text=True, packed=False)
+            data = t.tobytes()
+            file.write(data.decode("ascii") if as_text else data)
+        return n

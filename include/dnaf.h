@@ -1,0 +1,151 @@
+/*
+ * dnaf.h -- C ABI of the MI355X row generator (libdnaf_hip.so).
+ *
+ * Drop-in boundary for dna-factory's per-SNP row-generation hot path.  The
+ * reference has no FFI layer: the seam is two Python methods,
+ *   PopulationFactory.queue_vcf_snps(fam_data, work_q, result_p)  pop_factory.py:471-513  (worker)
+ *   PopulationFactory.write_vcf_snps(fam_data, snps, file)        pop_factory.py:417-469  (dispatcher)
+ * and this header is what a ctypes binding for that seam binds (see
+ * INTEGRATION.md for the reference-side stub).  Each entry point names the
+ * reference lines whose work it takes over.
+ *
+ * Conventions: every function returns DNAF_OK (0) or a negative DNAF_ERR_*;
+ * the message is available from dnaf_last_error().  No C++ exception crosses
+ * the ABI and nothing aborts.  The caller owns every host buffer it passes;
+ * no pointer is retained after a call returns.  The library owns the device
+ * buffers inside a context.  A context is bound to one GPU and is not
+ * thread-safe; different contexts may be used from different threads.
+ */
+#ifndef DNAF_H
+#define DNAF_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DNAF_ABI_VERSION 1
+
+#define DNAF_OK 0
+#define DNAF_ERR_BAD_ARG (-1)
+#define DNAF_ERR_HIP (-2)
+#define DNAF_ERR_OOM (-3)
+#define DNAF_ERR_UNSUPPORTED (-4)
+#define DNAF_ERR_STATE (-5)
+#define DNAF_ERR_THRESHOLD (-6) /* a roll could exceed the last cumulative frequency: the reference
+                                   would raise TypeError at pop_factory.py:489/494 */
+
+/* per-sample flag bits (SampleInfo.is_male / .is_control, pop_factory.py:47-71) */
+#define DNAF_SAMPLE_MALE 1u
+#define DNAF_SAMPLE_CONTROL 2u
+
+/* chromosome class of a row: everything is_haploid() and the female-on-Y rule
+ * look at (common/snp.py:102-109, pop_factory.py:481-484) */
+#define DNAF_CLASS_AUTOSOME 0u /* diploid for everyone                      */
+#define DNAF_CLASS_X 1u        /* haploid for males, diploid for females    */
+#define DNAF_CLASS_Y 2u        /* haploid for males, '.' for females        */
+#define DNAF_CLASS_MT 3u       /* haploid for everyone                      */
+
+#define DNAF_MAX_ALLELES 4
+
+/* RNG that stands in for numpy.random.rand(2*S) of pop_factory.py:477 */
+#define DNAF_RNG_PHILOX 0u  /* Philox4x32-10, one 32-bit word per draw; rocRAND sequence
+                               (seed, subsequence = RNG row, offset = 2*sample + allele)  */
+#define DNAF_RNG_MT19937 1u /* numpy legacy stream (53-bit doubles from MT19937)          */
+
+/* what dnaf_generate materialises */
+#define DNAF_OUT_TEXT 1u   /* VCF body lines, pop_factory.py:503-508                       */
+#define DNAF_OUT_PACKED 2u /* 2-bit genotype matrix [n_rows][ceil(S/16)] u32               */
+
+typedef struct dnaf_ctx dnaf_ctx;
+
+/* SNP table in structure-of-arrays form: the fields of SNPTuples
+ * (pop_factory.py:74-133) that the worker reads, for n_rows rows in output order. */
+typedef struct dnaf_snp_table {
+    uint64_t n_rows;
+    const int64_t* snp_id;        /* [n_rows] SNPTuples.id (matched against the forced set)            */
+    const uint8_t* chrom_class;   /* [n_rows] DNAF_CLASS_*                                             */
+    const uint8_t* n_alleles;     /* [n_rows] len(tuples), 1..DNAF_MAX_ALLELES                         */
+    const double* cum_freq;       /* [n_rows][DNAF_MAX_ALLELES] tuples[k][1]; unused entries ignored   */
+    const uint8_t* prefix_bytes;  /* rows' fixed columns "chrom\tpos\trsID\tREF\tALT\t40\tPASS\t.\tGT\t" */
+    const uint64_t* prefix_off;   /* [n_rows+1] offsets into prefix_bytes                              */
+} dnaf_snp_table;
+
+int dnaf_abi_version(void);
+int dnaf_device_count(int* count);
+
+int dnaf_create(int device, dnaf_ctx** out);
+int dnaf_destroy(dnaf_ctx* ctx);
+/* never NULL; valid until the next call on ctx (ctx == NULL: message of the last failed dnaf_create) */
+const char* dnaf_last_error(const dnaf_ctx* ctx);
+
+/* Sample table = the fam_data argument of queue_vcf_snps (pop_factory.py:471,
+ * :478-485): flags[i] = DNAF_SAMPLE_* bits of sample i, in fam order.
+ * Invalidates a previously set SNP table and forced set. */
+int dnaf_set_samples(dnaf_ctx* ctx, const uint8_t* flags, uint64_t n_samples);
+
+/* Forced ("deleterious") genotypes = SampleInfo.deleterious_snps of the case
+ * samples (pop_factory.py:485, :495-499), transposed by SNP: for slot k,
+ * samples carrier_idx[carrier_off[k] .. carrier_off[k+1]) carry SNP snp_ids[k].
+ * Control samples must not be listed (they are never forced, :485).
+ * n_slots == 0 clears the set.  Call after dnaf_set_samples and before
+ * dnaf_set_snps. */
+int dnaf_set_forced(dnaf_ctx* ctx, const int64_t* snp_ids, uint64_t n_slots,
+                    const uint64_t* carrier_off, const uint32_t* carrier_idx);
+
+/* RNG mode and seed.  rng_row0 = RNG row index of table row 0 (the global SNP
+ * row index when the table is one shard of a larger job), so any shard of a
+ * job reproduces the bytes of the whole job.  May be called at any time. */
+int dnaf_set_rng(dnaf_ctx* ctx, uint32_t mode, uint64_t seed, uint64_t rng_row0);
+
+/* Upload the SNP table (the work_q argument, pop_factory.py:474) and lay out
+ * the output: per-row integer thresholds, forced slot, text offsets. */
+int dnaf_set_snps(dnaf_ctx* ctx, const dnaf_snp_table* table);
+
+/* Bytes of VCF text that rows [row_begin, row_begin+n_rows) produce. */
+int dnaf_text_bytes(const dnaf_ctx* ctx, uint64_t row_begin, uint64_t n_rows, uint64_t* bytes);
+/* Start offsets of those rows relative to the first one: off[n_rows+1]. */
+int dnaf_row_offsets(const dnaf_ctx* ctx, uint64_t row_begin, uint64_t n_rows, uint64_t* off);
+
+/* Generate rows [row_begin, row_begin+n_rows) of the table into the
+ * context's device buffers (what = DNAF_OUT_* bits).  This is the worker
+ * loop pop_factory.py:474-509 for those rows.  Asynchronous on the
+ * context's stream; grows the output buffers if needed (a growth
+ * synchronises the device). */
+int dnaf_generate(dnaf_ctx* ctx, uint64_t row_begin, uint64_t n_rows, uint32_t what);
+int dnaf_sync(dnaf_ctx* ctx);
+
+/* Device time (HIP events on the context's stream) of the last
+ * dnaf_generate, in milliseconds.  Synchronises. */
+int dnaf_last_generate_ms(dnaf_ctx* ctx, float* ms);
+
+/* Per-kernel device timing over a region: dnaf_timing_begin() resets the
+ * recorder; every dnaf_generate() after it records a HIP event pair around
+ * its kernel on the context's stream (at most 4096 launches are recorded);
+ * dnaf_timing_end() synchronises and returns the summed kernel time, the
+ * number of launches recorded and the number of launches made. */
+int dnaf_timing_begin(dnaf_ctx* ctx);
+int dnaf_timing_end(dnaf_ctx* ctx, double* total_ms, uint64_t* n_recorded, uint64_t* n_launches);
+
+/* Copy the last generated range to host memory (synchronises).
+ * text: exactly dnaf_text_bytes() bytes; packed: n_rows*ceil(S/16) u32. */
+int dnaf_read_text(dnaf_ctx* ctx, void* dst, uint64_t dst_cap, uint64_t* n_bytes);
+int dnaf_read_packed(dnaf_ctx* ctx, uint32_t* dst, uint64_t dst_cap_words, uint64_t* n_words);
+
+/* Device pointers of the last generated range, for consumers that stay on
+ * the GPU (valid until the next dnaf_generate / dnaf_destroy). */
+int dnaf_device_buffers(dnaf_ctx* ctx, void** d_text, uint64_t* text_bytes, void** d_packed, uint64_t* packed_words);
+
+/* Host helper: format the fixed columns of each row exactly like
+ * pop_factory.py:503-507 ("%s\t%i\trs%s\t%s\t%s\t40\tPASS\t.\tGT\t").
+ * chrom/ref/alt are fixed-width, NUL-padded byte fields (numpy 'S<w>' arrays).
+ * Pass out == NULL to get only the offsets (off[n] = bytes needed). */
+int dnaf_format_prefixes(uint64_t n, const char* chrom, uint32_t chrom_w, const int64_t* pos, const int64_t* id,
+                         const char* ref, uint32_t ref_w, const char* alt, uint32_t alt_w, uint8_t* out,
+                         uint64_t out_cap, uint64_t* off);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DNAF_H */

@@ -245,8 +245,8 @@ int oracle_generate(const oracle_snp* snps, uint64_t n_rows, uint64_t rng_row0,
             }
             if (i) text[pos++] = '\t';              /* "\t".join(...)  :508 */
             if (n_out == 0) text[pos++] = '.';
-            else if (n_out == 1) pos += (uint64_t)sprintf(text + pos, "%d", a);
-            else pos += (uint64_t)sprintf(text + pos, "%d/%d", a, b);
+            else if (n_out == 1) text[pos++] = (char)('0' + a);      /* str(selected_nt), a < ORACLE_MAX_ALLELES */
+            else { text[pos++] = (char)('0' + a); text[pos++] = '/'; text[pos++] = (char)('0' + b); } /* "%i/%i" */
             if (prow) {
                 uint32_t bits = (n_out >= 1 && a != 0 ? 1u : 0u) | (n_out == 2 && b != 0 ? 2u : 0u);
                 prow[i / 16] |= bits << (2 * (i % 16));

@@ -1,0 +1,168 @@
+"""Parity of the HIP path (through the C ABI) with the CPU oracle and the committed reference fixtures.
+Bit-exact: text bytes, row offsets and the packed 2-bit matrix."""
+import numpy as np
+import pytest
+
+from helpers import golden_inputs, golden_names, load_golden, random_case
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def RowGenerator():
+    import __graft_entry__ as ge
+
+    ge.build()
+    from dna_factory_amd.rowgen import RowGenerator
+
+    return RowGenerator
+
+
+def oracle_run(orc, snps, samples, seed, rng_row0=0):
+    rec = orc.snp_records(snps)
+    sex, ctrl, off, ids = orc.sample_arrays(samples)
+    return orc.generate(rec, sex, ctrl, off, ids, rng_mode=orc.RNG_PHILOX, seed=seed, rng_row0=rng_row0)
+
+
+def check_case(RowGenerator, orc, snps, samples, seed, rng_row0=0):
+    with RowGenerator(device=0, seed=seed) as g:
+        g.set_samples(samples)
+        g.set_snps(snps, rng_row0=rng_row0)
+        text, off, packed = g.generate()
+        t_only, _, _ = g.generate(text=True, packed=False)
+        _, _, p_only = g.generate(text=False, packed=True)
+    want_text, want_off, want_packed = oracle_run(orc, snps, samples, seed, rng_row0)
+    assert np.array_equal(off, want_off)
+    assert text.tobytes() == want_text
+    assert np.array_equal(packed, want_packed)
+    assert t_only.tobytes() == want_text
+    assert np.array_equal(p_only, want_packed)
+
+
+@pytest.mark.parametrize("name", [n for n in golden_names() if not n.endswith("_mt")])
+def test_hip_matches_reference_fixture(RowGenerator, name):
+    doc = load_golden(name)
+    if doc.get("lines_philox") is None:
+        pytest.skip("fixture has no Philox lines")
+    snps, samples = golden_inputs(doc)
+    with RowGenerator(device=0, seed=doc["seed"]) as g:
+        g.set_samples(samples)
+        g.set_snps(snps)
+        assert g.lines() == doc["lines_philox"]
+
+
+@pytest.mark.parametrize("n_rows,S", [(1, 1), (7, 3), (33, 64), (50, 257), (40, 1000), (12, 4099), (3, 20000)])
+def test_hip_matches_oracle_random(RowGenerator, oracle, n_rows, S):
+    rs = np.random.RandomState(1000 + n_rows + S)
+    snps, samples = random_case(rs, n_rows, S)
+    check_case(RowGenerator, oracle, snps, samples, seed=int(rs.randint(0, 2**31)))
+
+
+def test_seed_and_row_index_use_all_64_bits(RowGenerator, oracle):
+    rs = np.random.RandomState(8)
+    snps, samples = random_case(rs, 9, 70)
+    check_case(RowGenerator, oracle, snps, samples, seed=0xFEDCBA9876543210, rng_row0=(1 << 32) - 4)
+
+
+def test_shards_reproduce_the_whole_job(RowGenerator, oracle):
+    """SNP-range shards (the multi-GPU partition) give the bytes of the unsharded job."""
+    rs = np.random.RandomState(11)
+    snps, samples = random_case(rs, 90, 150)
+    whole_text, whole_off, whole_packed = oracle_run(oracle, snps, samples, 77)
+    parts_t, parts_p = [], []
+    for b, e in ((0, 31), (31, 32), (32, 90)):
+        with RowGenerator(device=0, seed=77) as g:
+            g.set_samples(samples)
+            g.set_snps(snps[b:e], rng_row0=b)
+            t, _, p = g.generate()
+            parts_t.append(t.tobytes())
+            parts_p.append(p)
+    assert b"".join(parts_t) == whole_text
+    assert np.array_equal(np.concatenate(parts_p), whole_packed)
+
+
+def test_row_ranges_of_one_table(RowGenerator, oracle):
+    rs = np.random.RandomState(12)
+    snps, samples = random_case(rs, 60, 97)
+    want_text, want_off, want_packed = oracle_run(oracle, snps, samples, 5)
+    with RowGenerator(device=0, seed=5) as g:
+        g.set_samples(samples)
+        g.set_snps(snps)
+        for b, n in ((0, 0), (0, 1), (10, 25), (59, 1), (60, 0)):
+            t, off, p = g.generate(b, n)
+            assert t.tobytes() == want_text[int(want_off[b]): int(want_off[b + n])]
+            assert np.array_equal(off, want_off[b: b + n + 1] - want_off[b])
+            assert np.array_equal(p, want_packed[b: b + n])
+
+
+def test_write_vcf_snps_dropin(RowGenerator, oracle, tmp_path):
+    import io
+
+    rs = np.random.RandomState(13)
+    snps, samples = random_case(rs, 45, 83)
+    want_text, _, _ = oracle_run(oracle, snps, samples, 99)
+    with RowGenerator(device=0, seed=99) as g:
+        sink = io.BytesIO()
+        assert g.write_vcf_snps(samples, snps, sink, tile_rows=7) == 45
+        assert sink.getvalue() == want_text
+        tsink = io.StringIO()
+        g.write_vcf_snps(samples, snps, tsink)
+        assert tsink.getvalue() == want_text.decode()
+
+
+def test_errors_are_reported_not_fatal(RowGenerator):
+    from dna_factory_amd import capi
+
+    with RowGenerator(device=0, seed=1) as g:
+        with pytest.raises(capi.DnafError):
+            g.set_snps([(1, "1", 5, [("A", 0.9), ("T", 1.0)])])  # before set_samples
+        g.set_samples([(1, True, None)])
+        with pytest.raises(capi.DnafError) as e:
+            g.set_snps([(1, "1", 5, [("A", 0.5), ("T", 0.9)])])  # a roll above 0.9 has no allele
+        assert e.value.code == capi.ERR_THRESHOLD
+        with pytest.raises(capi.DnafError):
+            g.set_snps([(1, "1", 5, [("A", 0.1), ("C", 0.2), ("G", 0.3), ("T", 0.4), ("N", 1.0)])])
+        g.set_snps([(1, "1", 5, [("A", 0.5), ("T", 1.0)])])
+        with pytest.raises(capi.DnafError):
+            g.ctx.generate(0, 2)
+        with pytest.raises(capi.DnafError):
+            g.ctx.set_rng(capi.RNG_MT19937, 1)
+
+
+def test_full_size_properties(RowGenerator):
+    """BASELINE config shape S=20k: size-independent properties on a tile too big for the scalar oracle:
+    text is consistent with the packed matrix, cell grammar holds, and a forced SNP is 1/1 for its carriers."""
+    S, n = 20000, 2000
+    rs = np.random.RandomState(21)
+    from dna_factory_amd.tables import SampleTable, SnpTable
+
+    flags = (rs.rand(S) <= 0.5).astype(np.uint8) | (np.arange(S) < S // 2).astype(np.uint8) * 2
+    carriers = np.sort(rs.choice(np.arange(S // 2, S), 500, replace=False)).astype(np.uint32)
+    st = SampleTable(flags, [17], [0, len(carriers)], carriers)
+    maf = 0.005 * rs.randint(2, 100, n)
+    cum = np.ones((n, 4))
+    cum[:, 0] = 1 - maf
+    tb = SnpTable(np.arange(1, n + 1), np.full(n, b"1", dtype="S2"), np.arange(n) * 10 + 1, np.full(n, b"A", dtype="S1"),
+                  np.full(n, b"G", dtype="S1"), np.full(n, 2, np.uint8), cum)
+    with RowGenerator(device=0, seed=4) as g:
+        g.set_samples(st)
+        g.set_snps(tb)
+        text, off, packed = g.generate()
+    assert int(off[-1]) == len(text)
+    row_len = np.diff(off.astype(np.int64))
+    _, poff = tb.prefixes()
+    assert np.array_equal(row_len, np.diff(poff.astype(np.int64)) + 4 * S)
+    # decode cells of every row from the fixed-width layout
+    alt_freq = np.zeros(n)
+    for j in sorted(set(range(0, n, 97)) | {16}):
+        cells = text[int(off[j]) + int(poff[j + 1] - poff[j]): int(off[j + 1])].reshape(S, 4)
+        assert np.all(cells[:, 1] == ord("/")) and np.all(cells[:-1, 3] == 9) and cells[-1, 3] == 10
+        a, b = cells[:, 0] - 48, cells[:, 2] - 48
+        assert set(np.unique(a)) <= {0, 1} and set(np.unique(b)) <= {0, 1}
+        bits = (packed[j][:, None] >> (2 * np.arange(16))[None, :]).reshape(-1)[:S] & 3
+        assert np.array_equal(bits, a | (b << 1))
+        if j == 16:
+            assert np.all(a[carriers] == 1) and np.all(b[carriers] == 1)
+        ctrl = slice(0, S // 2)
+        alt_freq[j] = (a[ctrl].sum() + b[ctrl].sum()) / S
+        assert abs(alt_freq[j] - maf[j]) < 6 * np.sqrt(maf[j] * (1 - maf[j]) / S) + 1e-9
