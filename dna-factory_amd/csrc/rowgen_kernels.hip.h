@@ -121,7 +121,7 @@ __device__ __forceinline__ void row_segment(const GenParams& p, const RowRec& re
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const uint32_t sep = (4u * g + k == S - 1u) ? 0x0A000000u : 0x09000000u;
-                w[k] = 0x002F3030u + a[k] + (b[k] << 16) + sep;
+                w[k] = 0x00302F30u + a[k] + (b[k] << 16) + sep;
                 pk |= ((a[k] ? 1u : 0u) | (b[k] ? 2u : 0u)) << (2 * k);
             }
             if (TEXT) {
@@ -146,7 +146,7 @@ __device__ __forceinline__ void row_segment(const GenParams& p, const RowRec& re
                 } else {
                     pk |= ((a[k] ? 1u : 0u) | (b[k] ? 2u : 0u)) << (2 * k);
                     if (TEXT) {
-                        const uint32_t w = 0x002F3030u + a[k] + (b[k] << 16) + (last ? 0x0A000000u : 0x09000000u);
+                        const uint32_t w = 0x00302F30u + a[k] + (b[k] << 16) + (last ? 0x0A000000u : 0x09000000u);
                         store_unaligned<4>(dst, &w);
                         dst += 4;
                     }
