@@ -390,8 +390,9 @@ int dnaf_generate(dnaf_ctx* c, uint64_t row_begin, uint64_t n_rows, uint32_t wha
     p.key0 = (uint32_t)c->seed;
     p.key1 = (uint32_t)(c->seed >> 32);
     p.S = c->S; p.G = c->G; p.W = c->W;
-    p.seg_groups = 64u * c->seg_iters;
-    p.nseg = c->G ? (c->G + p.seg_groups - 1) / p.seg_groups : 1;
+    // split a row into nseg balanced segments of at most 64*seg_iters groups, each a multiple of 64 groups
+    p.nseg = c->G ? (c->G + 64u * c->seg_iters - 1) / (64u * c->seg_iters) : 1;
+    p.seg_groups = c->G ? ((c->G + p.nseg - 1) / p.nseg + 63u) / 64u * 64u : 64u;
     const uint64_t items = n_rows * p.nseg;
     const uint64_t blocks = (items + 3) / 4;
     if (blocks > 0x7FFFFFFFull) return fail(c, DNAF_ERR_UNSUPPORTED, "dnaf_generate: %llu workgroups; generate fewer rows per call", (unsigned long long)blocks);

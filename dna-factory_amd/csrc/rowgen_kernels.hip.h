@@ -4,11 +4,19 @@
 // owns one *group* of 4 consecutive samples per iteration: two Philox4x32-10
 // blocks give the 8 allele draws of the group (sample i, allele a <-> draw
 // 2i+a, the lane mapping of pop_factory.py:477/:486/:492), the cell rules of
-// pop_factory.py:479-499 turn them into 4 cells, and the lane stores 16
-// bytes of VCF text (autosome) plus one byte of the 2-bit matrix.  Lanes of a
-// wave therefore write 1 KiB of contiguous text per iteration.
+// pop_factory.py:479-499 turn them into 4 cells, and the lane stores its
+// cells' VCF text (16 bytes on an autosome) plus one byte of the 2-bit
+// matrix.  The 64 lanes of a wave therefore write 1 KiB of contiguous text
+// per iteration; row starts are byte-aligned only, and gfx950 runs the
+// resulting unaligned dwordx4 stores at ~94 % of the aligned rate
+// (profiles/r01_microbench.log), so no realignment pass is needed.
 //
-// No MFMA: the path is integer VALU (Philox) + streaming stores.
+// The row's record is wave-uniform and lives in SGPRs; the per-sample tables
+// (male / forced nibbles, X-row offsets) are read coalesced, one byte or
+// dword per lane per iteration, and stay L2-resident.
+//
+// No MFMA: the path is integer VALU (Philox: 20 v_mad_u64_u32 + 20 v_bitop3_b32
+// per block) + streaming stores.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -28,19 +36,19 @@ struct RowRec {
 static_assert(sizeof(RowRec) == 32, "RowRec must stay 32 bytes");
 
 struct GenParams {
-    const RowRec* recs;       // [table rows]
-    const uint8_t* prefix;    // prefix blob
-    const uint8_t* male_nib;  // [G] bit k = sample 4g+k is male
-    const uint32_t* xoff;     // [G+1] byte offset of group g's cells in an X row
-    const uint8_t* forced;    // [n_slots][G] bit k = sample 4g+k carries the slot's SNP
-    uint8_t* text;            // output text of this call (row_begin's first byte at text[0])
-    uint8_t* packed;          // output [n_rows][4*W] bytes
-    uint64_t text_base;       // recs[row_begin].text_off
-    uint64_t row_begin;       // first table row of this call
+    const RowRec* recs;        // [table rows]
+    const uint8_t* prefix;     // prefix blob
+    const uint8_t* male_nib;   // [G] bit k = sample 4g+k is male
+    const uint32_t* xoff;      // [G+1] byte offset of group g's cells in an X row
+    const uint8_t* forced;     // [n_slots][G] bit k = sample 4g+k carries the slot's SNP
+    uint8_t* text;             // output text of this call (row_begin's first byte at text[0])
+    uint8_t* packed;           // output [n_rows][4*W] bytes
+    uint64_t text_base;        // recs[row_begin].text_off
+    uint64_t row_begin;        // first table row of this call
     uint64_t n_rows;
-    uint64_t rng_row0;        // RNG row of table row 0
-    uint32_t key0, key1;      // Philox key = seed
-    uint32_t S, G, W;         // samples, groups of 4, packed words per row
+    uint64_t rng_row0;         // RNG row of table row 0
+    uint32_t key0, key1;       // Philox key = seed
+    uint32_t S, G, W;          // samples, groups of 4, packed words per row
     uint32_t nseg, seg_groups; // segments per row, groups per segment (multiple of 64)
 };
 
@@ -49,17 +57,18 @@ struct GenParams {
 #define PHILOX_W0 0x9E3779B9u
 #define PHILOX_W1 0xBB67AE85u
 
+// Philox4x32-10; the two 32x32->64 products of a round are one v_mad_u64_u32 each.
 __device__ __forceinline__ uint4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
                                                uint32_t k1)
 {
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
-        const uint32_t hi0 = __umulhi(PHILOX_M0, c0), lo0 = PHILOX_M0 * c0;
-        const uint32_t hi1 = __umulhi(PHILOX_M1, c2), lo1 = PHILOX_M1 * c2;
-        c0 = hi1 ^ c1 ^ k0;
-        c1 = lo1;
-        c2 = hi0 ^ c3 ^ k1;
-        c3 = lo0;
+        const uint64_t p0 = (uint64_t)PHILOX_M0 * c0;
+        const uint64_t p1 = (uint64_t)PHILOX_M1 * c2;
+        c0 = __builtin_amdgcn_bitop3_b32((uint32_t)(p1 >> 32), c1, k0, 0x96); // a ^ b ^ c in one v_bitop3_b32
+        c1 = (uint32_t)p1;
+        c2 = __builtin_amdgcn_bitop3_b32((uint32_t)(p0 >> 32), c3, k1, 0x96);
+        c3 = (uint32_t)p0;
         k0 += PHILOX_W0;
         k1 += PHILOX_W1;
     }
@@ -81,120 +90,171 @@ __device__ __forceinline__ void store_unaligned(uint8_t* dst, const void* src)
     __builtin_memcpy(dst, src, N); // byte-aligned destination: hardware unaligned global stores
 }
 
-// One row segment, chromosome class known (wave-uniform).
-template <bool TEXT, bool PACKED, bool MULTI>
-__device__ __forceinline__ void row_segment(const GenParams& p, const RowRec& rec, uint64_t row_local,
-                                            uint32_t g_begin, uint32_t g_end, uint32_t lane)
+struct SegCtx {
+    uint32_t t0, t1, t2;   // thresholds
+    uint32_t r_lo, r_hi;   // RNG row
+    uint32_t k0, k1;       // key
+    uint32_t S, G;
+    uint8_t* cells;        // first cell byte of the row
+    uint8_t* prow;         // packed row
+    const uint8_t* frow;   // forced nibbles of the row's slot or nullptr
+    const uint8_t* male_nib;
+    const uint32_t* xoff;
+};
+
+// The 8 allele indices of group g: a[k], b[k] = first / second allele of sample 4g+k,
+// with the forced genotype 1/1 applied (pop_factory.py:485, :495-499).
+template <bool MULTI>
+__device__ __forceinline__ void group_alleles(const SegCtx& c, uint32_t g, uint32_t& a0, uint32_t& a1, uint32_t& a2,
+                                              uint32_t& a3, uint32_t& b0, uint32_t& b1, uint32_t& b2, uint32_t& b3)
 {
-    const uint64_t rng_row = p.rng_row0 + p.row_begin + row_local;
-    const uint32_t r_lo = (uint32_t)rng_row, r_hi = (uint32_t)(rng_row >> 32);
-    const uint32_t t0 = rec.thr[0], t1 = rec.thr[1], t2 = rec.thr[2];
-    const uint32_t cls = rec.cls;
-    uint8_t* cells = p.text + (rec.text_off - p.text_base) + rec.prefix_len;
-    uint8_t* prow = p.packed + row_local * (uint64_t)p.W * 4u;
-    const uint8_t* frow = rec.slot >= 0 ? p.forced + (uint64_t)rec.slot * p.G : nullptr;
-    const uint32_t S = p.S;
-    const uint32_t g_stop = PACKED ? (g_end == p.G ? p.W * 4u : g_end) : g_end; // last segment also zeroes the pad bytes
-
-    for (uint32_t g = g_begin + lane; g < g_stop; g += 64) {
-        if (g >= p.G) { // pad bytes of the packed row
-            if (PACKED) prow[g] = 0;
-            continue;
-        }
-        const uint32_t nvalid = min(4u, S - 4u * g);
-        const uint32_t male = p.male_nib[g];
-        const uint32_t forced = frow ? frow[g] : 0u;
-        const uint4 x = philox4x32_10(2u * g, 0u, r_lo, r_hi, p.key0, p.key1);
-        const uint4 y = philox4x32_10(2u * g + 1u, 0u, r_lo, r_hi, p.key0, p.key1);
-        uint32_t a[4] = {pick<MULTI>(x.x, t0, t1, t2), pick<MULTI>(x.z, t0, t1, t2), pick<MULTI>(y.x, t0, t1, t2),
-                         pick<MULTI>(y.z, t0, t1, t2)};
-        uint32_t b[4] = {pick<MULTI>(x.y, t0, t1, t2), pick<MULTI>(x.w, t0, t1, t2), pick<MULTI>(y.y, t0, t1, t2),
-                         pick<MULTI>(y.w, t0, t1, t2)};
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-            if ((forced >> k) & 1u) { a[k] = 1u; b[k] = 1u; } // pop_factory.py:495-499
-
-        uint32_t pk = 0;
-        if (cls == 0u) {
-            // autosome: every cell "a/b" + separator = one dword
-            uint32_t w[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const uint32_t sep = (4u * g + k == S - 1u) ? 0x0A000000u : 0x09000000u;
-                w[k] = 0x00302F30u + a[k] + (b[k] << 16) + sep;
-                pk |= ((a[k] ? 1u : 0u) | (b[k] ? 2u : 0u)) << (2 * k);
-            }
-            if (TEXT) {
-                uint8_t* dst = cells + 16ull * g;
-                if (nvalid == 4u) store_unaligned<16>(dst, w);
-                else
-                    for (uint32_t k = 0; k < nvalid; ++k) store_unaligned<4>(dst + 4u * k, &w[k]);
-            }
-            if (nvalid < 4u) pk &= (1u << (2u * nvalid)) - 1u;
-        } else if (cls == 1u) {
-            // X: haploid "a" for males, diploid "a/b" for females (common/snp.py:102-109)
-            uint8_t* dst = cells + p.xoff[g];
-            for (uint32_t k = 0; k < nvalid; ++k) {
-                const uint32_t last = (4u * g + k == S - 1u);
-                if ((male >> k) & 1u) {
-                    pk |= (a[k] ? 1u : 0u) << (2 * k);
-                    if (TEXT) {
-                        const uint16_t h = (uint16_t)((0x30u + a[k]) | ((last ? 0x0Au : 0x09u) << 8));
-                        store_unaligned<2>(dst, &h);
-                        dst += 2;
-                    }
-                } else {
-                    pk |= ((a[k] ? 1u : 0u) | (b[k] ? 2u : 0u)) << (2 * k);
-                    if (TEXT) {
-                        const uint32_t w = 0x00302F30u + a[k] + (b[k] << 16) + (last ? 0x0A000000u : 0x09000000u);
-                        store_unaligned<4>(dst, &w);
-                        dst += 4;
-                    }
-                }
-            }
-        } else {
-            // Y: '.' for females first (pop_factory.py:481-484), haploid for males; MT: haploid for everyone
-            uint8_t* dst = cells + 8ull * g;
-            for (uint32_t k = 0; k < nvalid; ++k) {
-                const uint32_t last = (4u * g + k == S - 1u);
-                uint32_t ch;
-                if (cls == 2u && !((male >> k) & 1u)) ch = 0x2Eu; // '.'
-                else {
-                    ch = 0x30u + a[k];
-                    pk |= (a[k] ? 1u : 0u) << (2 * k);
-                }
-                if (TEXT) {
-                    const uint16_t h = (uint16_t)(ch | ((last ? 0x0Au : 0x09u) << 8));
-                    store_unaligned<2>(dst + 2u * k, &h);
-                }
-            }
-        }
-        if (PACKED) prow[g] = (uint8_t)pk;
+    const uint4 x = philox4x32_10(2u * g, 0u, c.r_lo, c.r_hi, c.k0, c.k1);
+    const uint4 y = philox4x32_10(2u * g + 1u, 0u, c.r_lo, c.r_hi, c.k0, c.k1);
+    a0 = pick<MULTI>(x.x, c.t0, c.t1, c.t2); b0 = pick<MULTI>(x.y, c.t0, c.t1, c.t2);
+    a1 = pick<MULTI>(x.z, c.t0, c.t1, c.t2); b1 = pick<MULTI>(x.w, c.t0, c.t1, c.t2);
+    a2 = pick<MULTI>(y.x, c.t0, c.t1, c.t2); b2 = pick<MULTI>(y.y, c.t0, c.t1, c.t2);
+    a3 = pick<MULTI>(y.z, c.t0, c.t1, c.t2); b3 = pick<MULTI>(y.w, c.t0, c.t1, c.t2);
+    if (c.frow) { // wave-uniform
+        const uint32_t f = c.frow[g];
+        if (f & 1u) a0 = b0 = 1u;
+        if (f & 2u) a1 = b1 = 1u;
+        if (f & 4u) a2 = b2 = 1u;
+        if (f & 8u) a3 = b3 = 1u;
     }
+}
+
+__device__ __forceinline__ uint32_t nz(uint32_t v) { return v ? 1u : 0u; }
+
+#define DIPLOID_CELL(a, b, sep) (0x00302F30u + (a) + ((b) << 16) + ((sep) << 24)) /* "a/b" + separator */
+#define HAPLOID_CELL(ch, sep) ((ch) | ((sep) << 8))                                /* "a" + separator   */
+
+// Full iteration of an autosome row: every lane has 4 samples, none of them the row's last.
+template <bool TEXT, bool PACKED, bool MULTI>
+__device__ __forceinline__ void autosome_fast(const SegCtx& c, uint32_t g)
+{
+    uint32_t a0, a1, a2, a3, b0, b1, b2, b3;
+    group_alleles<MULTI>(c, g, a0, a1, a2, a3, b0, b1, b2, b3);
+    if (TEXT) {
+        const uint4 w = make_uint4(DIPLOID_CELL(a0, b0, 9u), DIPLOID_CELL(a1, b1, 9u), DIPLOID_CELL(a2, b2, 9u),
+                                   DIPLOID_CELL(a3, b3, 9u));
+        store_unaligned<16>(c.cells + 16ull * g, &w);
+    }
+    if (PACKED)
+        c.prow[g] = (uint8_t)(nz(a0) | nz(b0) << 1 | nz(a1) << 2 | nz(b1) << 3 | nz(a2) << 4 | nz(b2) << 5 | nz(a3) << 6 |
+                              nz(b3) << 7);
+}
+
+// Full iteration of a Y / MT row: 4 haploid cells = 8 bytes per lane.
+template <bool TEXT, bool PACKED, bool MULTI, bool IS_Y>
+__device__ __forceinline__ void haploid_fast(const SegCtx& c, uint32_t g)
+{
+    uint32_t a0, a1, a2, a3, b0, b1, b2, b3;
+    group_alleles<MULTI>(c, g, a0, a1, a2, a3, b0, b1, b2, b3);
+    uint32_t m = 0xFu;
+    if (IS_Y) m = c.male_nib[g]; // '.' for females comes first (pop_factory.py:481-484)
+    const uint32_t c0 = (m & 1u) ? 0x30u + a0 : 0x2Eu, c1 = (m & 2u) ? 0x30u + a1 : 0x2Eu;
+    const uint32_t c2 = (m & 4u) ? 0x30u + a2 : 0x2Eu, c3 = (m & 8u) ? 0x30u + a3 : 0x2Eu;
+    if (TEXT) {
+        const uint2 w = make_uint2(HAPLOID_CELL(c0, 9u) | HAPLOID_CELL(c1, 9u) << 16,
+                                   HAPLOID_CELL(c2, 9u) | HAPLOID_CELL(c3, 9u) << 16);
+        store_unaligned<8>(c.cells + 8ull * g, &w);
+    }
+    if (PACKED)
+        c.prow[g] = (uint8_t)((m & 1u ? nz(a0) : 0u) | (m & 2u ? nz(a1) : 0u) << 2 | (m & 4u ? nz(a2) : 0u) << 4 |
+                              (m & 8u ? nz(a3) : 0u) << 6);
+}
+
+// Any iteration of any row class: handles the row's last group (newline, fewer than 4
+// samples), the pad bytes of the packed row, and the variable-width cells of an X row.
+template <bool TEXT, bool PACKED, bool MULTI>
+__device__ __forceinline__ void general_group(const SegCtx& c, uint32_t cls, uint32_t g)
+{
+    if (g >= c.G) { // lanes past the last group only zero the pad bytes of the packed row
+        if (PACKED) c.prow[g] = 0;
+        return;
+    }
+    uint32_t a[4], b[4];
+    group_alleles<MULTI>(c, g, a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]);
+    const uint32_t male = c.male_nib[g];
+    uint8_t* dst = c.cells + (cls == 0u ? 16ull * g : (cls == 1u ? (uint64_t)c.xoff[g] : 8ull * g));
+    uint32_t pk = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t i = 4u * g + (uint32_t)k;
+        if (i < c.S) {
+            const uint32_t sep = (i == c.S - 1u) ? 0x0Au : 0x09u; // "\t".join(...) + "\n", pop_factory.py:508
+            const bool is_male = (male >> k) & 1u;
+            const bool missing = cls == 2u && !is_male;                           // pop_factory.py:481-484
+            const bool haploid = cls >= 2u || (cls == 1u && is_male);             // common/snp.py:102-109
+            if (missing) {
+                if (TEXT) { const uint16_t h = (uint16_t)HAPLOID_CELL(0x2Eu, sep); store_unaligned<2>(dst, &h); dst += 2; }
+            } else if (haploid) {
+                pk |= nz(a[k]) << (2 * k);
+                if (TEXT) { const uint16_t h = (uint16_t)HAPLOID_CELL(0x30u + a[k], sep); store_unaligned<2>(dst, &h); dst += 2; }
+            } else {
+                pk |= (nz(a[k]) | nz(b[k]) << 1) << (2 * k);
+                if (TEXT) { const uint32_t w = DIPLOID_CELL(a[k], b[k], sep); store_unaligned<4>(dst, &w); dst += 4; }
+            }
+        }
+    }
+    if (PACKED) c.prow[g] = (uint8_t)pk;
+}
+
+template <bool TEXT, bool PACKED, bool MULTI>
+__device__ __forceinline__ void row_segment(const SegCtx& c, uint32_t cls, uint32_t g_begin, uint32_t g_end,
+                                            uint32_t g_stop, uint32_t lane)
+{
+    // groups [g_begin, g_fast) are complete and do not hold the row's last sample
+    const uint32_t g_last = c.S ? (c.S - 1u) / 4u : 0u;
+    const uint32_t g_fast = min(g_end, g_last);
+    uint32_t gb = g_begin;
+    if (cls == 0u)
+        for (; gb + 64u <= g_fast; gb += 64u) autosome_fast<TEXT, PACKED, MULTI>(c, gb + lane);
+    else if (cls == 2u)
+        for (; gb + 64u <= g_fast; gb += 64u) haploid_fast<TEXT, PACKED, MULTI, true>(c, gb + lane);
+    else if (cls == 3u)
+        for (; gb + 64u <= g_fast; gb += 64u) haploid_fast<TEXT, PACKED, MULTI, false>(c, gb + lane);
+    for (; gb < g_stop; gb += 64u)
+        if (gb + lane < g_stop) general_group<TEXT, PACKED, MULTI>(c, cls, gb + lane);
 }
 
 template <bool TEXT, bool PACKED>
 __global__ __launch_bounds__(256) void rowgen_kernel(const GenParams p)
 {
     const uint32_t lane = threadIdx.x & 63u;
-    const uint64_t item = (uint64_t)blockIdx.x * 4u + (threadIdx.x >> 6);
+    // wave-uniform work item -> scalar registers
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint64_t item = (uint64_t)blockIdx.x * 4u + wave;
     const uint64_t row_local = item / p.nseg;
     const uint32_t seg = (uint32_t)(item % p.nseg);
     if (row_local >= p.n_rows) return;
     const RowRec rec = p.recs[p.row_begin + row_local];
+    uint8_t* row_text = p.text + (rec.text_off - p.text_base);
 
     if (TEXT && seg == 0) {
         // the row's fixed columns (pop_factory.py:503-507), formatted on the host; S == 0: line = prefix + "\n"
-        uint8_t* dst = p.text + (rec.text_off - p.text_base);
         const uint8_t* src = p.prefix + rec.prefix_off;
-        for (uint32_t i = lane; i < rec.prefix_len; i += 64) dst[i] = src[i];
-        if (p.S == 0 && lane == 0) dst[rec.prefix_len] = 0x0A;
+        for (uint32_t i = lane; i < rec.prefix_len; i += 64) row_text[i] = src[i];
+        if (p.S == 0 && lane == 0) row_text[rec.prefix_len] = 0x0A;
     }
     const uint32_t g_begin = seg * p.seg_groups;
     if (g_begin >= p.G && !(PACKED && seg == 0)) return;
     const uint32_t g_end = min(p.G, g_begin + p.seg_groups);
-    if (rec.n_alleles > 2) row_segment<TEXT, PACKED, true>(p, rec, row_local, g_begin, g_end, lane);
-    else row_segment<TEXT, PACKED, false>(p, rec, row_local, g_begin, g_end, lane);
+    const uint32_t g_stop = (PACKED && g_end == p.G) ? p.W * 4u : g_end; // the last segment also zeroes the pad bytes
+
+    const uint64_t rng_row = p.rng_row0 + p.row_begin + row_local;
+    SegCtx c;
+    c.t0 = rec.thr[0]; c.t1 = rec.thr[1]; c.t2 = rec.thr[2];
+    c.r_lo = (uint32_t)rng_row; c.r_hi = (uint32_t)(rng_row >> 32);
+    c.k0 = p.key0; c.k1 = p.key1;
+    c.S = p.S; c.G = p.G;
+    c.cells = row_text + rec.prefix_len;
+    c.prow = p.packed + row_local * (uint64_t)p.W * 4u;
+    c.frow = rec.slot >= 0 ? p.forced + (uint64_t)rec.slot * p.G : nullptr;
+    c.male_nib = p.male_nib;
+    c.xoff = p.xoff;
+    if (rec.n_alleles > 2) row_segment<TEXT, PACKED, true>(c, rec.cls, g_begin, g_end, g_stop, lane);
+    else row_segment<TEXT, PACKED, false>(c, rec.cls, g_begin, g_end, g_stop, lane);
 }
 
 } // namespace dnaf

@@ -23,7 +23,10 @@ __device__ __forceinline__ uint4 philox(uint32_t c0, uint32_t c1, uint32_t c2, u
             asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, 0" : "=v"(p1) : "v"(c2), "s"(0xCD9E8D57u) : "vcc");
             hi0 = (uint32_t)(p0 >> 32); lo0 = (uint32_t)p0; hi1 = (uint32_t)(p1 >> 32); lo1 = (uint32_t)p1;
         }
-        c0 = hi1 ^ c1 ^ k0; c1 = lo1; c2 = hi0 ^ c3 ^ k1; c3 = lo0;
+        if (VARIANT == 2) {
+            c0 = __builtin_amdgcn_bitop3_b32(hi1, c1, k0, 0x96); c1 = lo1;
+            c2 = __builtin_amdgcn_bitop3_b32(hi0, c3, k1, 0x96); c3 = lo0;
+        } else { c0 = hi1 ^ c1 ^ k0; c1 = lo1; c2 = hi0 ^ c3 ^ k1; c3 = lo0; }
         k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
     }
     return make_uint4(c0, c1, c2, c3);
@@ -82,17 +85,18 @@ int main()
     uint32_t* d_out; CK(hipMalloc(&d_out, 1 << 26));
     float ms;
     // ---- Philox rate ----
-    for (int variant = 0; variant < 2; ++variant) {
+    for (int variant = 0; variant < 3; ++variant) {
         for (int blocks_per_cu : {4, 8}) {
             const uint32_t blocks = 256 * blocks_per_cu, iters = 2000;
             for (int rep = 0; rep < 3; ++rep) {
                 CK(hipEventRecord(e0));
                 if (variant == 0) hipLaunchKernelGGL(k_philox<0>, dim3(blocks), dim3(256), 0, 0, d_out, iters, 1u, 2u);
-                else hipLaunchKernelGGL(k_philox<1>, dim3(blocks), dim3(256), 0, 0, d_out, iters, 1u, 2u);
+                else if (variant == 1) hipLaunchKernelGGL(k_philox<1>, dim3(blocks), dim3(256), 0, 0, d_out, iters, 1u, 2u);
+                else hipLaunchKernelGGL(k_philox<2>, dim3(blocks), dim3(256), 0, 0, d_out, iters, 1u, 2u);
                 CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms, e0, e1));
             }
             double calls = (double)blocks * 256 * iters;
-            printf("philox variant=%s blocks/CU=%d: %.3f ms  %.3e calls/s  %.3e draws32/s\n", variant ? "mad_u64_u32" : "mulhi+mullo",
+            printf("philox variant=%s blocks/CU=%d: %.3f ms  %.3e calls/s  %.3e draws32/s\n", variant == 0 ? "mulhi+mullo" : variant == 1 ? "mad_u64_u32" : "mad_u64_u32+bitop3",
                    blocks_per_cu, ms, calls / (ms * 1e-3), 4 * calls / (ms * 1e-3));
         }
     }
