@@ -81,7 +81,11 @@ def cpu_baseline(tb, st, seed, target_seconds):
 
     orc.build()
     S = len(st)
-    cores = max(1, (os.cpu_count() or 2) - 1)
+    try:
+        avail = len(os.sched_getaffinity(0))  # the cores this process may actually run on
+    except (AttributeError, OSError):
+        avail = os.cpu_count() or 2
+    cores = max(1, avail - 1)  # the reference's advice: never more workers than cores - 1 (README.md:59-68)
     # oracle inputs from the SoA tables
     def records(lo, hi):
         rec = np.zeros(hi - lo, dtype=orc.SNP_DTYPE)
@@ -162,6 +166,10 @@ def main():
     gen.set_snps(tb, rng_row0=rank * rows)  # this rank's SNP range of the global table
     what = {"text+packed": capi.OUT_TEXT | capi.OUT_PACKED, "text": capi.OUT_TEXT, "packed": capi.OUT_PACKED}[a.what]
     n_tiles = max(1, rows // a.tile_rows)
+
+    # size the output buffers for the largest tile up front: no allocation inside the timed region
+    gen.ctx.reserve_output(max(gen.ctx.text_bytes(t * a.tile_rows, a.tile_rows) for t in range(n_tiles)),
+                           a.tile_rows * gen.words_per_row)
 
     def step(i):
         gen.ctx.generate((i % n_tiles) * a.tile_rows, a.tile_rows, what)

@@ -28,6 +28,7 @@ OUT_TEXT, OUT_PACKED = 1, 2
 SYMBOLS = [
     "dnaf_abi_version", "dnaf_device_count", "dnaf_create", "dnaf_destroy", "dnaf_last_error", "dnaf_set_samples",
     "dnaf_set_forced", "dnaf_set_rng", "dnaf_set_snps", "dnaf_text_bytes", "dnaf_row_offsets", "dnaf_generate",
+    "dnaf_reserve_output",
     "dnaf_sync", "dnaf_last_generate_ms", "dnaf_timing_begin", "dnaf_timing_end", "dnaf_read_text", "dnaf_read_packed", "dnaf_device_buffers",
     "dnaf_format_prefixes",
 ]
@@ -72,6 +73,7 @@ def _load():
         "dnaf_text_bytes": (ci, [vp, u64, u64, vp]),
         "dnaf_row_offsets": (ci, [vp, u64, u64, vp]),
         "dnaf_generate": (ci, [vp, u64, u64, u32]),
+        "dnaf_reserve_output": (ci, [vp, u64, u64]),
         "dnaf_sync": (ci, [vp]),
         "dnaf_last_generate_ms": (ci, [vp, vp]),
         "dnaf_timing_begin": (ci, [vp]),
@@ -202,6 +204,9 @@ class Context:
 
     def generate(self, row_begin, n_rows, what=OUT_TEXT | OUT_PACKED):
         self._check(lib.dnaf_generate(self._h, row_begin, n_rows, what))
+
+    def reserve_output(self, text_bytes, packed_words):
+        self._check(lib.dnaf_reserve_output(self._h, int(text_bytes), int(packed_words)))
 
     def sync(self):
         self._check(lib.dnaf_sync(self._h))

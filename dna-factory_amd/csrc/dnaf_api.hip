@@ -345,6 +345,34 @@ int dnaf_row_offsets(const dnaf_ctx* c, uint64_t row_begin, uint64_t n_rows, uin
     return DNAF_OK;
 }
 
+static int grow_outputs(dnaf_ctx* c, uint64_t tbytes, uint64_t pbytes)
+{
+    if (tbytes > c->text_cap) {
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        dev_free(c->d_text);
+        c->text_cap = 0;
+        c->have_output = false;
+        HIP_TRY(c, hipMalloc((void**)&c->d_text, tbytes + 64)); // slack: nothing is stored past tbytes
+        c->text_cap = tbytes;
+    }
+    if (pbytes > c->packed_cap) {
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        dev_free(c->d_packed);
+        c->packed_cap = 0;
+        c->have_output = false;
+        HIP_TRY(c, hipMalloc((void**)&c->d_packed, pbytes + 64));
+        c->packed_cap = pbytes;
+    }
+    return DNAF_OK;
+}
+
+int dnaf_reserve_output(dnaf_ctx* c, uint64_t text_bytes, uint64_t packed_words)
+{
+    if (!c) return DNAF_ERR_BAD_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    return grow_outputs(c, text_bytes, packed_words * 4u);
+}
+
 int dnaf_generate(dnaf_ctx* c, uint64_t row_begin, uint64_t n_rows, uint32_t what)
 {
     if (!c) return DNAF_ERR_BAD_ARG;
@@ -355,20 +383,7 @@ int dnaf_generate(dnaf_ctx* c, uint64_t row_begin, uint64_t n_rows, uint32_t wha
     HIP_TRY(c, hipSetDevice(c->device));
     const uint64_t tbytes = c->h_text_off[(size_t)(row_begin + n_rows)] - c->h_text_off[(size_t)row_begin];
     const uint64_t pbytes = n_rows * (uint64_t)c->W * 4u;
-    if ((what & DNAF_OUT_TEXT) && tbytes > c->text_cap) {
-        HIP_TRY(c, hipStreamSynchronize(c->stream));
-        dev_free(c->d_text);
-        c->text_cap = 0;
-        HIP_TRY(c, hipMalloc((void**)&c->d_text, tbytes + 64)); // slack: nothing is stored past tbytes
-        c->text_cap = tbytes;
-    }
-    if ((what & DNAF_OUT_PACKED) && pbytes > c->packed_cap) {
-        HIP_TRY(c, hipStreamSynchronize(c->stream));
-        dev_free(c->d_packed);
-        c->packed_cap = 0;
-        HIP_TRY(c, hipMalloc((void**)&c->d_packed, pbytes + 64));
-        c->packed_cap = pbytes;
-    }
+    if (int rc = grow_outputs(c, (what & DNAF_OUT_TEXT) ? tbytes : 0, (what & DNAF_OUT_PACKED) ? pbytes : 0)) return rc;
     c->last_begin = row_begin;
     c->last_rows = n_rows;
     c->last_what = what;

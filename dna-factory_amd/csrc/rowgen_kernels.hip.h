@@ -103,7 +103,7 @@ struct SegCtx {
 };
 
 // The 8 allele indices of group g: a[k], b[k] = first / second allele of sample 4g+k,
-// with the forced genotype 1/1 applied (pop_factory.py:485, :495-499).
+// with the forced genotype 1/1 applied (pop_factory.py:485, :495-499).  General form (any allele count).
 template <bool MULTI>
 __device__ __forceinline__ void group_alleles(const SegCtx& c, uint32_t g, uint32_t& a0, uint32_t& a1, uint32_t& a2,
                                               uint32_t& a3, uint32_t& b0, uint32_t& b1, uint32_t& b2, uint32_t& b3)
@@ -128,23 +128,109 @@ __device__ __forceinline__ uint32_t nz(uint32_t v) { return v ? 1u : 0u; }
 #define DIPLOID_CELL(a, b, sep) (0x00302F30u + (a) + ((b) << 16) + ((sep) << 24)) /* "a/b" + separator */
 #define HAPLOID_CELL(ch, sep) ((ch) | ((sep) << 8))                                /* "a" + separator   */
 
-// Full iteration of an autosome row: every lane has 4 samples, none of them the row's last.
+// Biallelic rows: the diploid cell "a/b\t" of one sample straight from its two draws.
+#define CELL00 0x09302F30u /* "0/0\t" */
+__device__ __forceinline__ uint32_t biallelic_cell(uint32_t ua, uint32_t ub, uint32_t t0)
+{
+    return (ub > t0 ? CELL00 + 0x10000u : CELL00) + (ua > t0 ? 1u : 0u);
+}
+
+// d[k] = "a/b\t" of sample 4g+k on a biallelic row, forced genotypes applied.
+__device__ __forceinline__ void biallelic_cells(const SegCtx& c, uint32_t g, uint32_t& d0, uint32_t& d1, uint32_t& d2,
+                                                uint32_t& d3)
+{
+    const uint4 x = philox4x32_10(2u * g, 0u, c.r_lo, c.r_hi, c.k0, c.k1);
+    const uint4 y = philox4x32_10(2u * g + 1u, 0u, c.r_lo, c.r_hi, c.k0, c.k1);
+    d0 = biallelic_cell(x.x, x.y, c.t0);
+    d1 = biallelic_cell(x.z, x.w, c.t0);
+    d2 = biallelic_cell(y.x, y.y, c.t0);
+    d3 = biallelic_cell(y.z, y.w, c.t0);
+    if (c.frow) { // wave-uniform; forced = "1/1", pop_factory.py:495-499
+        const uint32_t f = c.frow[g];
+        if (f & 1u) d0 = CELL00 + 0x10001u;
+        if (f & 2u) d1 = CELL00 + 0x10001u;
+        if (f & 4u) d2 = CELL00 + 0x10001u;
+        if (f & 8u) d3 = CELL00 + 0x10001u;
+    }
+}
+
+// 2-bit codes of 4 biallelic cells: the cells are CELL00 + a + (b << 16), so the shifted sum is
+// linear in the allele bits: a_k lands on bit 2k and b_k on bit 16 + 2k of (sum - constant).
+__device__ __forceinline__ uint32_t biallelic_spread(uint32_t d0, uint32_t d1, uint32_t d2, uint32_t d3)
+{
+    const uint32_t K = CELL00 + (CELL00 << 2) + (CELL00 << 4) + (CELL00 << 6);
+    return d0 + (d1 << 2) + (d2 << 4) + (d3 << 6) - K;
+}
+
+// Autosome row, groups that are complete and do not hold the row's last sample.
 template <bool TEXT, bool PACKED, bool MULTI>
 __device__ __forceinline__ void autosome_fast(const SegCtx& c, uint32_t g)
 {
-    uint32_t a0, a1, a2, a3, b0, b1, b2, b3;
-    group_alleles<MULTI>(c, g, a0, a1, a2, a3, b0, b1, b2, b3);
+    uint32_t d0, d1, d2, d3, pk;
+    if (!MULTI) {
+        biallelic_cells(c, g, d0, d1, d2, d3);
+        const uint32_t D = biallelic_spread(d0, d1, d2, d3);
+        pk = D | (D >> 15);
+    } else {
+        uint32_t a0, a1, a2, a3, b0, b1, b2, b3;
+        group_alleles<true>(c, g, a0, a1, a2, a3, b0, b1, b2, b3);
+        d0 = DIPLOID_CELL(a0, b0, 9u); d1 = DIPLOID_CELL(a1, b1, 9u);
+        d2 = DIPLOID_CELL(a2, b2, 9u); d3 = DIPLOID_CELL(a3, b3, 9u);
+        pk = nz(a0) | nz(b0) << 1 | nz(a1) << 2 | nz(b1) << 3 | nz(a2) << 4 | nz(b2) << 5 | nz(a3) << 6 | nz(b3) << 7;
+    }
     if (TEXT) {
-        const uint4 w = make_uint4(DIPLOID_CELL(a0, b0, 9u), DIPLOID_CELL(a1, b1, 9u), DIPLOID_CELL(a2, b2, 9u),
-                                   DIPLOID_CELL(a3, b3, 9u));
+        const uint4 w = make_uint4(d0, d1, d2, d3);
         store_unaligned<16>(c.cells + 16ull * g, &w);
     }
-    if (PACKED)
-        c.prow[g] = (uint8_t)(nz(a0) | nz(b0) << 1 | nz(a1) << 2 | nz(b1) << 3 | nz(a2) << 4 | nz(b2) << 5 | nz(a3) << 6 |
-                              nz(b3) << 7);
+    if (PACKED) c.prow[g] = (uint8_t)pk;
 }
 
-// Full iteration of a Y / MT row: 4 haploid cells = 8 bytes per lane.
+// X row (biallelic), complete groups without the row's last sample: males are haploid "a\t",
+// females diploid "a/b\t" (common/snp.py:102-109), so a lane's 4 cells take 8..16 bytes starting at
+// xoff[g].  The cells are shifted together in registers; the lane then stores the first 8 and the
+// last 8 bytes of its run (the two stores overlap with identical bytes when the run is shorter than 16).
+template <bool TEXT, bool PACKED>
+__device__ __forceinline__ void x_fast(const SegCtx& c, uint32_t g)
+{
+    uint32_t d0, d1, d2, d3;
+    biallelic_cells(c, g, d0, d1, d2, d3);
+    const uint32_t m = c.male_nib[g];
+    if (TEXT) {
+        const bool m0 = m & 1u, m1 = m & 2u, m2 = m & 4u, m3 = m & 8u;
+        // haploid cell = first character of the diploid cell + '\t'
+        const uint32_t c0 = m0 ? (d0 & 0xFFu) | 0x0900u : d0, c1 = m1 ? (d1 & 0xFFu) | 0x0900u : d1;
+        const uint32_t c2 = m2 ? (d2 & 0xFFu) | 0x0900u : d2, c3 = m3 ? (d3 & 0xFFu) | 0x0900u : d3;
+        // R = cells back to back, built from the last cell: R = (R << width_k) | cell_k
+        uint32_t r0 = c3, r1, r2, r3;
+        r1 = m2 ? r0 >> 16 : r0;
+        r0 = m2 ? (r0 << 16) | c2 : c2;
+        r2 = m1 ? r1 >> 16 : r1;
+        r1 = m1 ? __builtin_amdgcn_alignbit(r1, r0, 16) : r0;
+        r0 = m1 ? (r0 << 16) | c1 : c1;
+        r3 = m0 ? r2 >> 16 : r2;
+        r2 = m0 ? __builtin_amdgcn_alignbit(r2, r1, 16) : r1;
+        r1 = m0 ? __builtin_amdgcn_alignbit(r1, r0, 16) : r0;
+        r0 = m0 ? (r0 << 16) | c0 : c0;
+        const uint32_t s = 8u - 2u * (uint32_t)__builtin_popcount(m); // run length - 8, in bytes
+        const uint32_t q = s >> 2, sh = (s & 2u) << 3;
+        const uint32_t t0 = q == 0u ? r0 : (q == 1u ? r1 : r2);
+        const uint32_t t1 = q == 0u ? r1 : (q == 1u ? r2 : r3);
+        const uint32_t t2 = q == 0u ? r2 : (q == 1u ? r3 : 0u);
+        uint8_t* dst = c.cells + c.xoff[g];
+        const uint2 head = make_uint2(r0, r1);
+        const uint2 tail = make_uint2(__builtin_amdgcn_alignbit(t1, t0, sh), __builtin_amdgcn_alignbit(t2, t1, sh));
+        store_unaligned<8>(dst, &head);
+        store_unaligned<8>(dst + s, &tail);
+    }
+    if (PACKED) {
+        const uint32_t D = biallelic_spread(d0, d1, d2, d3);
+        uint32_t sp = (m | (m << 2)) & 0x33u; // male bit k -> bit 2k
+        sp = (sp | (sp << 1)) & 0x55u;
+        c.prow[g] = (uint8_t)((D | (D >> 15)) & ~(sp << 1)); // haploid: no second allele
+    }
+}
+
+// Y / MT row, complete groups without the row's last sample: 4 haploid cells = 8 bytes per lane.
 template <bool TEXT, bool PACKED, bool MULTI, bool IS_Y>
 __device__ __forceinline__ void haploid_fast(const SegCtx& c, uint32_t g)
 {
@@ -164,8 +250,8 @@ __device__ __forceinline__ void haploid_fast(const SegCtx& c, uint32_t g)
                               (m & 8u ? nz(a3) : 0u) << 6);
 }
 
-// Any iteration of any row class: handles the row's last group (newline, fewer than 4
-// samples), the pad bytes of the packed row, and the variable-width cells of an X row.
+// Any group of any row class, cell by cell: used for the row's last group (newline, fewer than 4
+// samples), the pad bytes of the packed row, and multi-allelic X rows.
 template <bool TEXT, bool PACKED, bool MULTI>
 __device__ __forceinline__ void general_group(const SegCtx& c, uint32_t cls, uint32_t g)
 {
@@ -204,17 +290,25 @@ template <bool TEXT, bool PACKED, bool MULTI>
 __device__ __forceinline__ void row_segment(const SegCtx& c, uint32_t cls, uint32_t g_begin, uint32_t g_end,
                                             uint32_t g_stop, uint32_t lane)
 {
-    // groups [g_begin, g_fast) are complete and do not hold the row's last sample
+    // groups [g_begin, g_fast) are complete and do not hold the row's last sample: class-specialised loops
     const uint32_t g_last = c.S ? (c.S - 1u) / 4u : 0u;
     const uint32_t g_fast = min(g_end, g_last);
     uint32_t gb = g_begin;
-    if (cls == 0u)
-        for (; gb + 64u <= g_fast; gb += 64u) autosome_fast<TEXT, PACKED, MULTI>(c, gb + lane);
-    else if (cls == 2u)
-        for (; gb + 64u <= g_fast; gb += 64u) haploid_fast<TEXT, PACKED, MULTI, true>(c, gb + lane);
-    else if (cls == 3u)
-        for (; gb + 64u <= g_fast; gb += 64u) haploid_fast<TEXT, PACKED, MULTI, false>(c, gb + lane);
-    for (; gb < g_stop; gb += 64u)
+    if (cls == 0u) {
+        for (; gb < g_fast; gb += 64u)
+            if (gb + lane < g_fast) autosome_fast<TEXT, PACKED, MULTI>(c, gb + lane);
+    } else if (cls == 1u && !MULTI) {
+        for (; gb < g_fast; gb += 64u)
+            if (gb + lane < g_fast) x_fast<TEXT, PACKED>(c, gb + lane);
+    } else if (cls == 2u) {
+        for (; gb < g_fast; gb += 64u)
+            if (gb + lane < g_fast) haploid_fast<TEXT, PACKED, MULTI, true>(c, gb + lane);
+    } else if (cls == 3u) {
+        for (; gb < g_fast; gb += 64u)
+            if (gb + lane < g_fast) haploid_fast<TEXT, PACKED, MULTI, false>(c, gb + lane);
+    }
+    // what is left: the row's last group and the packed pad bytes (or a whole multi-allelic X segment)
+    for (gb = (cls == 1u && MULTI) ? g_begin : max(g_begin, g_fast); gb < g_stop; gb += 64u)
         if (gb + lane < g_stop) general_group<TEXT, PACKED, MULTI>(c, cls, gb + lane);
 }
 

@@ -114,6 +114,8 @@ int dnaf_row_offsets(const dnaf_ctx* ctx, uint64_t row_begin, uint64_t n_rows, u
  * context's stream; grows the output buffers if needed (a growth
  * synchronises the device). */
 int dnaf_generate(dnaf_ctx* ctx, uint64_t row_begin, uint64_t n_rows, uint32_t what);
+/* Size the output buffers ahead of time so that no later dnaf_generate has to grow them. */
+int dnaf_reserve_output(dnaf_ctx* ctx, uint64_t text_bytes, uint64_t packed_words);
 int dnaf_sync(dnaf_ctx* ctx);
 
 /* Device time (HIP events on the context's stream) of the last
