@@ -85,6 +85,12 @@ def cpu_baseline(tb, st, seed, target_seconds):
         avail = len(os.sched_getaffinity(0))  # the cores this process may actually run on
     except (AttributeError, OSError):
         avail = os.cpu_count() or 2
+    try:  # a container may see every core but be limited to a CPU quota (cgroup v2 cpu.max = "quota period")
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            avail = max(1, min(avail, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
     cores = max(1, avail - 1)  # the reference's advice: never more workers than cores - 1 (README.md:59-68)
     # oracle inputs from the SoA tables
     def records(lo, hi):
