@@ -203,13 +203,9 @@ def main():
     t1 = time.perf_counter()
     barrier()
     kern_ms, n_rec, n_launch = gen.ctx.timing_end()
-    elapsed = t1 - t0
-    if dist is not None:
-        import torch
+    from dna_factory_amd.sharding import max_over_ranks
 
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = max_over_ranks(t1 - t0, dist, "cuda" if dist is not None else None)
 
     if rank == 0:
         # algorithmic bytes of one launch: packed row + text row + 32-byte SNP record, per row

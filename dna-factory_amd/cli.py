@@ -1,0 +1,212 @@
+"""Command line of the generator: the flag surface of the reference's pop_factory.py (pop_factory.py:638-693)
+and its output directory layout, with the VCF body produced on MI355X GPUs.
+
+Reference flags keep their names, dests and defaults (pinned by the reference's own
+test/unit/pop_factory_test.py:80-104).  Additive flags: --seed, --rng, --devices, --tile-rows, --threads,
+--compat-deleterious-file-bug.
+"""
+import argparse
+import os
+import random
+import sys
+import threading
+import time
+from datetime import datetime
+
+import numpy
+
+ROOT_DIR = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+OUTPUT_DIR = os.path.join(ROOT_DIR, "populations")
+
+
+def parse_cmd_args(args):
+    p = argparse.ArgumentParser(fromfile_prefix_chars="@", prog="DNA Factory",
+                                description="Generates genetic populations using simulated SNP data.")
+    p.add_argument("-s", type=int, dest="size", help="size of afflicted/case group", required=True)
+    p.add_argument("-c", type=int, dest="control_size", help="size of control group", required=True)
+    p.add_argument("-x", type=int, dest="max_snps", help="max number of snps to load/generate")
+    p.add_argument("-p", type=str, default="deleterious.yml", dest="deleterious_config",
+                   help="location of deleterious config yaml file (default is deleterious.yml)")
+    p.add_argument("-f", type=float, default=0.005, dest="min_freq",
+                   help="min minor allele frequency for a SNP to be included, default is 0.005")
+    p.add_argument("-m", type=float, default=0.5, dest="male_odds",
+                   help="odds of a population member being male (default 0.5)")
+    p.add_argument("-n", type=int, default=2, dest="num_processes",
+                   help="number of worker processes of the reference; accepted for compatibility, the GPU path "
+                        "has no worker processes")
+    p.add_argument("-z", type=int, dest="compression_level", default=6, choices=range(1, 10),
+                   help="gzip compression level (1=least 9=most) default 6")
+    p.add_argument("-l", action="store_const", const=False, default=True, dest="generate_snps",
+                   help="load from the RefSNP database instead of simulated snps (not supported by this build)")
+    p.add_argument("--deleterious_file", type=str,
+                   help="<path> to a deleterious.json file that specifies the exact snps to use as deleterious")
+    p.add_argument("--snps_file", type=str, help="<path> location of snps.json.gz file to use as selected snps")
+    p.add_argument("--outdir", type=str, help="<path> directory to use for output files")
+    p.add_argument("--offset", type=int,
+                   help="offset to add to all sample ids. Useful for creating VCF files that can be merged")
+    # --- extensions ---
+    p.add_argument("--seed", type=int, help="RNG seed (default: wall clock HHMMSS, like the reference); also seeds "
+                                            "python's `random` so that a run is reproducible")
+    p.add_argument("--rng", choices=["philox", "mt19937"], default="philox", help="row RNG (DESIGN.md section 2)")
+    p.add_argument("--devices", type=str, default="0", help="comma-separated GPU ids; SNP ranges are sharded over them")
+    p.add_argument("--tile-rows", type=int, default=0, help="SNP rows generated per kernel launch (0 = auto)")
+    p.add_argument("--threads", type=int, default=0, help="BGZF compression threads per shard (0 = auto)")
+    p.add_argument("--compat-deleterious-file-bug", action="store_true",
+                   help="keep the reference's behaviour for --deleterious_file: ids stay strings, so nothing is forced")
+    return p.parse_args(args)
+
+
+def _auto_tile_rows(n_samples, n_rows):
+    per_row = 64 + 4 * max(n_samples, 1)
+    return max(1, min(max(n_rows, 1), (512 << 20) // per_row))
+
+
+def _generate_shard(device, seed, rng, st, tb, row_lo, row_hi, tile_rows, sink, progress):
+    """Rows [row_lo, row_hi) of the table on one GPU -> sink.write(bytes), in order."""
+    from .rowgen import RowGenerator
+
+    with RowGenerator(device=device, seed=seed, rng=rng) as gen:
+        gen.set_samples(st)
+        gen.set_snps(tb.slice(row_lo, row_hi), rng_row0=row_lo)
+        n = row_hi - row_lo
+        for b in range(0, n, tile_rows):
+            m = min(tile_rows, n - b)
+            text, _, _ = gen.generate(b, m, text=True, packed=False)
+            sink.write(text)
+            progress(m)
+
+
+def write_vcf(path, header, st, tb, seed, rng, devices, compresslevel, tile_rows=0, threads=0):
+    """population.vcf.gz = header + one body line per SNP (output_vcf_population, pop_factory.py:385-415).
+    With several devices each GPU writes its contiguous SNP range to its own BGZF shard; shards are then
+    concatenated (BGZF members are independent), ending with a single EOF block."""
+    from . import bgzf
+
+    n = len(tb)
+    if n == 0:
+        raise Exception("No SNPs to Process! Exiting.")  # pop_factory.py:395-396
+    tile_rows = tile_rows or _auto_tile_rows(len(st), n)
+    threads = threads or max(1, min(16, (os.cpu_count() or 4) // max(1, len(devices))))
+    done = [0]
+    lock = threading.Lock()
+    t0 = time.time()
+
+    def progress(m):
+        with lock:
+            done[0] += m
+            print("%s Output %i/%i VCF lines." % (datetime.now().strftime("%Y-%m-%d %H:%M:%S"), done[0], n), flush=True)
+
+    print("Outputing VCF lines", flush=True)
+    if len(devices) == 1:
+        with bgzf.BgzfWriter(path, compresslevel=compresslevel, threads=threads) as f:
+            f.write(header)
+            _generate_shard(devices[0], seed, rng, st, tb, 0, n, tile_rows, f, progress)
+    else:
+        from .sharding import shard_bounds
+
+        G = len(devices)
+        bounds = shard_bounds(n, G)
+        shard_paths = ["%s.shard%d" % (path, g) for g in range(G)]
+        errors = []
+
+        def run(g):
+            try:
+                with open(shard_paths[g], "wb") as raw:
+                    w = bgzf.BgzfWriter(fileobj=_NoClose(raw), compresslevel=compresslevel, threads=threads)
+                    if g == 0:
+                        w.write(header)
+                    _generate_shard(devices[g], seed, rng, st, tb, bounds[g], bounds[g + 1], tile_rows, w, progress)
+                    w.flush()  # no EOF block inside a shard
+                    w.close_pool()
+            except BaseException as e:  # surfaced in the parent, never swallowed
+                errors.append(e)
+
+        ths = [threading.Thread(target=run, args=(g,)) for g in range(G)]
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join()
+        if errors:
+            raise errors[0]
+        with open(path, "wb") as out:
+            for sp in shard_paths:
+                with open(sp, "rb") as f:
+                    while True:
+                        chunk = f.read(8 << 20)
+                        if not chunk:
+                            break
+                        out.write(chunk)
+                os.remove(sp)
+            out.write(bgzf.EOF_BLOCK)
+    print("Finished VCF file output. (%.1f s)" % (time.time() - t0), flush=True)
+
+
+class _NoClose:
+    def __init__(self, f):
+        self._f = f
+
+    def write(self, b):
+        return self._f.write(b)
+
+    def flush(self):
+        self._f.flush()
+
+    def close(self):
+        pass
+
+
+def generate_population(args):
+    from . import population as pop
+
+    t_start = time.time()
+    seed = args.seed if args.seed is not None else int(datetime.now().strftime("%H%M%S"))  # pop_factory.py:235
+    numpy.random.seed(seed)
+    if args.seed is not None:
+        random.seed(seed)
+    if args.outdir:
+        outdir = args.outdir if args.outdir.endswith(os.path.sep) else args.outdir + os.path.sep
+    else:
+        outdir = os.path.join(OUTPUT_DIR, datetime.now().strftime("%Y%m%d%H%M")) + os.path.sep
+    os.makedirs(outdir, exist_ok=True)
+
+    if args.snps_file:
+        tb = pop.load_snps_file(args.snps_file)
+    elif args.generate_snps:
+        if not args.max_snps or args.max_snps < 1:
+            raise SystemExit("-x <max_snps> is required when SNPs are simulated")
+        tb = pop.generate_snp_table(args.max_snps, min_maf=args.min_freq)
+    else:
+        raise SystemExit("-l (load from the RefSNP database) is not supported: the database path is outside this "
+                         "generator's scope; use simulated SNPs or --snps_file")
+    tb = pop.sort_snp_table(tb)
+    if not args.snps_file:
+        t = time.time()
+        pop.write_snps_file(tb, outdir + "snps.json.gz")
+        print("Time to write snps file %0.4f seconds" % (time.time() - t), flush=True)
+
+    if args.deleterious_file:
+        groups = pop.load_deleterious_json(args.deleterious_file, int_keys=not args.compat_deleterious_file_bug)
+    else:
+        t = time.time()
+        groups = pop.pick_deleterious(tb, args.deleterious_config)
+        pop.write_deleterious_json(groups, outdir + "deleterious.json")
+        print("Elapsed pick_deleterious_snps %0.2f sec" % (time.time() - t), flush=True)
+
+    if len(tb) == 0:
+        raise Exception("No SNPs to Process! Exiting.")
+    st = pop.build_samples(groups, args.control_size, args.size, args.male_odds, outdir, offset=args.offset or 0)
+    header = pop.vcf_header(st.person_id)
+    devices = [int(d) for d in args.devices.split(",") if d != ""]
+    write_vcf(outdir + "population.vcf.gz", header, st, tb, seed, args.rng, devices, args.compression_level,
+              tile_rows=args.tile_rows, threads=args.threads)
+    print("Finished Generating Population in %0.4f secs." % (time.time() - t_start), flush=True)
+    return outdir
+
+
+def main(sys_args):
+    args = parse_cmd_args(sys_args)
+    return generate_population(args)
+
+
+if __name__ == "__main__":
+    main(sys.argv[1:])

@@ -1,0 +1,232 @@
+"""Host side of a population run: everything around the row generator that the reference does in
+`PopulationFactory.generate_population` (pop_factory.py:225-256) -- SNP list, deleterious picks, sample table,
+side files, VCF header -- on structure-of-arrays data, with the output layouts of SURVEY Appendix A.
+
+Seed-level compatibility of the feeders: every random decision is taken with the same numpy legacy
+(`numpy.random.*`, global MT19937) and stdlib `random` calls, in the same order and on the same arguments, as the
+reference takes them.  After `numpy.random.seed(k)` / `random.seed(j)` the SNP list, `deleterious.json`,
+`population.fam` and `pop_deleterious.txt` therefore come out byte-identical to the reference's
+(tests/test_population_host.py checks this against tests/golden/full_flow_120x400).
+"""
+import gzip
+import json
+import os
+import random
+from datetime import datetime
+
+import numpy
+import numpy as np
+
+from . import genome
+from .tables import SampleTable, SnpTable
+
+# ---------------------------------------------------------------------------------------------------------
+# SNP list
+# ---------------------------------------------------------------------------------------------------------
+
+
+def generate_snp_table(size, min_maf=0.005):
+    """The synthetic SNP list of SnpFactory.random_snp_tuples (pop_factory.py:172-193), sorted like
+    pop_factory.py:245, as an SnpTable.  Consumes the global numpy / `random` streams exactly like the reference:
+    choice(chromosomes, p) -> choice(mafs, p) -> random(size) -> choice(nucleotides) -> one random.choice per SNP."""
+    maf_vals, pdf = genome.load_maf_pdf()
+    start = 0
+    for i, m in enumerate(maf_vals):  # first index with min_maf <= m, pop_factory.py:161-165
+        if min_maf <= m:
+            start = i
+            break
+    chrom_idx = numpy.random.choice(len(genome.CHROMOSOME_LIST), size=size, p=genome.CHROMOSOME_PROB)
+    mafs = numpy.random.choice(maf_vals[start:], size=size, p=pdf[start:] * 1 / numpy.sum(pdf[start:]))
+    position_randoms = numpy.random.random(size)
+    ref_idx = numpy.random.choice(4, size=size)  # same draws as choice(["A","T","C","G"], size)
+    others = [[n for n in range(4) if n != r] for r in range(4)]  # remaining_nt after .remove(ref), in list order
+    alt_idx = np.fromiter((random.choice(others[r]) for r in ref_idx), dtype=np.int64, count=size)
+    max_pos = np.array([genome.CHROMOSOME_MAX_POSITION[c] for c in genome.CHROMOSOME_LIST], dtype=np.int64)
+    position = (position_randoms * max_pos[chrom_idx]).astype(np.int64)  # int(rand * max), pop_factory.py:186
+    names = np.array([c.encode() for c in genome.CHROMOSOME_LIST], dtype="S2")
+    nt = np.array([c.encode() for c in genome.NUCLEOTIDES], dtype="S1")
+    cum = np.ones((size, 4), dtype=np.float64)
+    cum[:, 0] = 1 - mafs
+    ids = np.arange(1, size + 1, dtype=np.int64)
+    tb = SnpTable(ids, names[chrom_idx], position, nt[ref_idx], nt[alt_idx], np.full(size, 2, np.uint8), cum)
+    return sort_snp_table(tb)
+
+
+def sort_snp_table(tb):
+    """ordered_snps.sort(key=(chromosome, position)) -- chromosome compares as a *string* (SURVEY Q9); stable."""
+    uniq, inv = np.unique(tb.chrom, return_inverse=True)  # uniq is sorted bytewise = Python str order for ASCII
+    order = np.lexsort((tb.position, inv))
+    return tb.take(order)
+
+
+def _float_repr_column(values):
+    """repr() of each float64 via the distinct values (MAF tables have < 100 of them)."""
+    uniq, inv = np.unique(values, return_inverse=True)
+    reprs = np.array([repr(float(u)) for u in uniq])
+    return reprs[inv]
+
+
+def write_snps_file(tb, path):
+    """snps.json.gz: one `str(SNPTuples)` per line (pop_factory.py:118-124, :258-262), gzip level 5."""
+    n = len(tb)
+    with gzip.open(path, "wt", compresslevel=5) as f:
+        step = 200000
+        for b in range(0, n, step):
+            e = min(n, b + step)
+            lines = []
+            ref = tb.ref[b:e].astype("U")
+            chrom = tb.chrom[b:e].astype("U")
+            alts = [a.split(",") for a in tb.alt[b:e].astype("U")]
+            for j in range(e - b):
+                na = int(tb.n_alleles[b + j])
+                tuples = {ref[j]: float(tb.cum[b + j, 0])}
+                for k in range(1, na):
+                    tuples[alts[j][k - 1]] = float(tb.cum[b + j, k])
+                lines.append(json.dumps({"id": int(tb.snp_id[b + j]), "chromosome": chrom[j],
+                                         "position": int(tb.position[b + j]), "tuples": tuples}))
+            f.write("\n".join(lines) + "\n")
+
+
+def load_snps_file(path):
+    """Read snps.json.gz (SNPTuples.from_json, pop_factory.py:126-133, :264-272): key order of "tuples" is allele order."""
+    snps = []
+    with gzip.open(path, "rt") as f:
+        for line in f:
+            o = json.loads(line)
+            snps.append((o["id"], o["chromosome"], o["position"], list(o.get("tuples", {}).items())))
+    return SnpTable.from_snps(snps)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# Deleterious groups (pop_factory.py:541-635)
+# ---------------------------------------------------------------------------------------------------------
+
+
+class DeleteriousGroup:
+    def __init__(self, name, population_weight):
+        self.deleterious = {}  # snp id -> mutation weight, in pick order
+        self.name = name
+        self.population_weight = population_weight
+
+    def to_json(self):
+        return json.dumps({"deleterious": {str(k): v for k, v in self.deleterious.items()}, "name": self.name,
+                           "population_weight": self.population_weight})
+
+    @classmethod
+    def from_json(cls, line, int_keys=True):
+        """int_keys=False keeps the reference's behaviour (pop_factory.py:613-619): keys stay strings and never
+        match an int SNP id, so nothing is forced."""
+        o = json.loads(line)
+        g = cls(o["name"], o["population_weight"])
+        for k, w in o["deleterious"].items():
+            g.deleterious[int(k) if int_keys else k] = w
+        return g
+
+    def select_mutations(self):
+        """Shuffle, then take mutations until their weights reach 1 (pop_factory.py:621-635)."""
+        items = list(self.deleterious.items())
+        random.shuffle(items)
+        picked, agg = {}, 0
+        for k, w in items:
+            picked[k] = w
+            agg += w
+            if agg >= 1:
+                break
+        return picked
+
+
+def _filtered_ids(tb, lo, hi):
+    """snp_ids_from_list (pop_factory.py:549-558): filter on (minor.cum - ref.cum) only if min > 0 or max < 0.5."""
+    if lo > 0 or hi < 0.5:
+        diff = tb.cum[:, 1] - tb.cum[:, 0]
+        keep = (lo <= diff) & (diff <= hi)
+        return tb.snp_id[keep]
+    return tb.snp_id
+
+
+def pick_deleterious(tb, config_path):
+    """YAML config -> ordered {name: DeleteriousGroup} (pick_deleterious_snps / from_yml / init_with_snps,
+    pop_factory.py:521-538, :560-608).  One numpy.random.choice(ids, k, replace=False) per group instance."""
+    import yaml
+
+    with open(config_path, "r") as f:
+        cfg = yaml.safe_load(f)
+    groups = {}
+    for name, attr in cfg.items():
+        lo, hi = 0, 1
+        if attr.get("min_minor_allele_freq"):
+            if not 0 < attr["min_minor_allele_freq"] < 0.5:
+                raise Exception("min_minor_allele_freq must be between 0 and 0.5. yml value = {}".format(attr["min_minor_allele_freq"]))
+            lo = attr["min_minor_allele_freq"]
+        if attr.get("max_minor_allele_freq"):
+            if not 0 < attr["max_minor_allele_freq"] < 0.5:
+                raise Exception("max_minor_allele_freq must be between 0 and 0.5. yml value = {}".format(attr["max_minor_allele_freq"]))
+            hi = attr["max_minor_allele_freq"]
+        n_inst = int(attr["num_instances"]) if attr.get("num_instances") else 1
+        ids = _filtered_ids(tb, lo, hi)
+        weights = attr["mutation_weights"]
+        for i in range(n_inst):
+            g = DeleteriousGroup("%s-%s" % (name, i), attr["population_weight"])
+            if len(ids) == 0:
+                raise Exception("No SNPs in list to choose from. SNPs must have all been filtered out by deleterious config.")
+            for w, sid in zip(weights, numpy.random.choice(a=ids, size=len(weights), replace=False)):
+                g.deleterious[int(sid)] = w
+            groups[g.name] = g
+    return groups
+
+
+def write_deleterious_json(groups, path):
+    with open(path, "w") as f:
+        for g in groups.values():
+            f.write(g.to_json() + "\n")
+
+
+def load_deleterious_json(path, int_keys=True):
+    groups = {}
+    with open(path, "rt") as f:
+        for line in f:
+            g = DeleteriousGroup.from_json(line, int_keys=int_keys)
+            groups[g.name] = g
+    return groups
+
+
+# ---------------------------------------------------------------------------------------------------------
+# Sample table, FAM and side files (pop_factory.py:333-383)
+# ---------------------------------------------------------------------------------------------------------
+
+
+def build_samples(groups, control_size, test_size, male_odds, outdir, offset=0):
+    """pick_deleterious_groups (random.choices) -> generate_fam_file (numpy rand for sex; select_mutations per case);
+    writes population.fam and pop_deleterious.txt; returns (SampleTable, person ids)."""
+    glist = list(groups.values())
+    chosen = random.choices(population=glist, weights=[g.population_weight for g in glist], k=test_size) if test_size else []
+    n = control_size + test_size
+    randoms = numpy.random.rand(n)
+    sex = np.where(randoms <= male_odds, 1, 2)
+    person = np.empty(n, dtype=np.int64)
+    person[:control_size] = 100000 + offset + np.arange(1, control_size + 1)
+    person[control_size:] = 500000 + offset + np.arange(1, test_size + 1)
+    carried = [None] * n
+    with open(os.path.join(outdir, "pop_deleterious.txt"), "w") as pp:
+        for j in range(test_size):
+            picked = chosen[j].select_mutations()
+            carried[control_size + j] = picked
+            pp.write("%i\t%s\t" % (person[control_size + j], chosen[j].name) + "\t".join("rs" + str(k) for k in picked) + "\n")
+    with open(os.path.join(outdir, "population.fam"), "w") as f:
+        for i in range(n):
+            f.write("%i\t%i\t%i\t%i\t%i\t%i\t\n" % (i + 1 + offset * 2, person[i], 0, 0, sex[i], 1 if i < control_size else 2))
+    st = SampleTable.from_samples((int(sex[i]), i < control_size, carried[i]) for i in range(n))
+    st.person_id = person
+    return st
+
+
+def vcf_header(person_ids, now=None):
+    """gen_vcf_header, pop_factory.py:36-44."""
+    now = now or datetime.now()
+    return ("##fileformat=VCFv4.3\n"
+            "##filedate=%s\n" % now.strftime("%Y%m%d %H:%M")
+            + "##source=PopFactory\n"
+            + '##FILTER=<ID=q10,Description="Quality below 10">\n'
+            + '##FORMAT=<ID=GT,Number=1,Type=String,Description="Genotype">\n'
+            + "#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\t"
+            + "\t".join(str(int(p)) for p in person_ids) + "\n")

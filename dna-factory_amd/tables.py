@@ -96,6 +96,11 @@ class SnpTable:
             self._prefix = capi.format_prefixes(self.chrom, self.position, self.snp_id, self.ref, self.alt)
         return self._prefix
 
+    def take(self, order):
+        """Rows re-ordered / selected by an index array."""
+        return SnpTable(self.snp_id[order], self.chrom[order], self.position[order], self.ref[order], self.alt[order],
+                        self.n_alleles[order], self.cum[order])
+
     def slice(self, begin, end):
         return SnpTable(self.snp_id[begin:end], self.chrom[begin:end], self.position[begin:end], self.ref[begin:end],
                         self.alt[begin:end], self.n_alleles[begin:end], self.cum[begin:end])

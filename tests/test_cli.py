@@ -1,0 +1,123 @@
+"""Command line: flag surface (the reference's own parse test) and, on a GPU, the output directory end to end."""
+import gzip
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def cli():
+    import __graft_entry__ as ge
+
+    ge.build()
+    from dna_factory_amd import cli
+
+    return cli
+
+
+def test_parse_args_like_the_reference(cli):
+    # test/unit/pop_factory_test.py:80-104, verbatim expectations
+    cmd = ("-s 10 -c 20 -n 5 -z 3 -p path_config.yml -f 0.1 -m 0.7 -x 2500 -l "
+           "--deleterious_file /home/ochrzan/workspace/deleterious.json "
+           "--offset 300 --snps_file my_snps.json --outdir myoutput/tuesday")
+    a = cli.parse_cmd_args(cmd.split(" "))
+    assert (a.size, a.control_size, a.num_processes, a.compression_level) == (10, 20, 5, 3)
+    assert (a.deleterious_config, a.min_freq, a.male_odds, a.max_snps) == ("path_config.yml", 0.1, 0.7, 2500)
+    assert a.generate_snps is False
+    assert a.deleterious_file == "/home/ochrzan/workspace/deleterious.json"
+    assert (a.offset, a.snps_file, a.outdir) == (300, "my_snps.json", "myoutput/tuesday")
+    a = cli.parse_cmd_args("-s 10 -c 20 -x 2500".split(" "))
+    assert a.deleterious_file is None
+    # defaults of pop_factory.py:646-659
+    assert (a.deleterious_config, a.min_freq, a.male_odds, a.num_processes, a.compression_level, a.generate_snps) == (
+        "deleterious.yml", 0.005, 0.5, 2, 6, True)
+    with pytest.raises(SystemExit):
+        cli.parse_cmd_args("-s 10 -c 20 -z 10".split(" "))
+    with pytest.raises(SystemExit):
+        cli.parse_cmd_args("-c 20".split(" "))
+
+
+def test_args_from_file(cli, tmp_path):
+    f = tmp_path / "args.txt"
+    f.write_text("-s\n5\n-c\n6\n-x\n77\n")
+    a = cli.parse_cmd_args(["@" + str(f)])  # fromfile_prefix_chars='@', pop_factory.py:639
+    assert (a.size, a.control_size, a.max_snps) == (5, 6, 77)
+
+
+def _run_cli(args, cwd=REPO):
+    env = dict(os.environ, PYTHONPATH=REPO)
+    return subprocess.run([sys.executable, os.path.join(REPO, "pop_factory.py")] + args, cwd=cwd, env=env,
+                          capture_output=True, text=True, timeout=600)
+
+
+def _expected_body(outdir, seed, orc):
+    """Rebuild the worker's inputs from the side files the run wrote, and run the CPU oracle on them."""
+    snps = []
+    for line in gzip.open(os.path.join(outdir, "snps.json.gz"), "rt"):
+        o = json.loads(line)
+        snps.append((o["id"], o["chromosome"], o["position"], list(o["tuples"].items())))
+    carried = {}
+    for line in open(os.path.join(outdir, "pop_deleterious.txt")):
+        parts = line.rstrip("\n").split("\t")
+        carried[int(parts[0])] = [int(x[2:]) for x in parts[2:] if x]
+    samples = []
+    for line in open(os.path.join(outdir, "population.fam")):
+        fid, iid, _, _, sex, pheno = line.split("\t")[:6]
+        ctrl = pheno == "1"
+        samples.append((int(sex), ctrl, None if ctrl else carried[int(iid)]))
+    rec = orc.snp_records(snps)
+    sex, ctrl, off, ids = orc.sample_arrays(samples)
+    text, _, _ = orc.generate(rec, sex, ctrl, off, ids, rng_mode=orc.RNG_PHILOX, seed=seed)
+    return text, samples
+
+
+@pytest.mark.gpu
+def test_cli_end_to_end_matches_oracle(oracle, tmp_path):
+    out = tmp_path / "run1"
+    r = _run_cli(["-s", "70", "-c", "90", "-x", "1500", "-f", "0.01", "-n", "1", "-z", "4", "--seed", "4242",
+                  "--outdir", str(out), "--tile-rows", "400"])
+    assert r.returncode == 0, r.stderr
+    for name in ("population.vcf.gz", "population.fam", "pop_deleterious.txt", "deleterious.json", "snps.json.gz"):
+        assert os.path.getsize(out / name) > 0
+    vcf = gzip.open(out / "population.vcf.gz", "rb").read()
+    head, body = vcf.split(b"#CHROM", 1)
+    col_line, body = body.split(b"\n", 1)
+    assert head.startswith(b"##fileformat=VCFv4.3\n##filedate=") and b"##source=PopFactory\n" in head
+    want, samples = _expected_body(str(out), 4242, oracle)
+    assert body == want
+    iids = [l.split("\t")[1] for l in open(out / "population.fam")]
+    assert col_line == ("\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\t" + "\t".join(iids)).encode()
+    assert len(samples) == 160 and body.count(b"\n") == 1500
+    # BGZF structure: every member carries the BC field, the file ends with the 28-byte EOF block
+    from dna_factory_amd import bgzf
+
+    sizes = bgzf.block_sizes(str(out / "population.vcf.gz"))
+    assert sizes[-1] == 28 and max(sizes) <= 65536
+
+    # same seed, SNP list and deleterious set on two shards (two contexts) -> identical decompressed VCF body
+    out2 = tmp_path / "run2"
+    r = _run_cli(["-s", "70", "-c", "90", "--seed", "4242", "--snps_file", str(out / "snps.json.gz"),
+                  "--deleterious_file", str(out / "deleterious.json"), "--devices", "0,0", "--outdir", str(out2)])
+    assert r.returncode == 0, r.stderr
+    # (sample sexes / carried sets are re-drawn from the same seeds in the same order only if the feeder call
+    # sequence is identical; here the SNP generation is skipped, so compare against this run's own side files)
+    vcf2 = gzip.open(out2 / "population.vcf.gz", "rb").read()
+    body2 = vcf2.split(b"#CHROM", 1)[1].split(b"\n", 1)[1]
+    import shutil
+
+    shutil.copy(out / "snps.json.gz", out2 / "snps.json.gz")
+    want2, _ = _expected_body(str(out2), 4242, oracle)
+    assert body2 == want2
+    assert bgzf.block_sizes(str(out2 / "population.vcf.gz"))[-1] == 28
+
+
+@pytest.mark.gpu
+def test_cli_refuses_the_database_path(tmp_path):
+    r = _run_cli(["-s", "1", "-c", "1", "-l", "--outdir", str(tmp_path / "x")])
+    assert r.returncode != 0 and "not supported" in (r.stderr + r.stdout)

@@ -1,0 +1,107 @@
+"""Host-side feeders against the reference's own feeders (fixture full_flow_120x400, produced by
+oracle/make_golden.py from SnpFactory / pick_deleterious_snps / generate_fam_file with fixed seeds)."""
+import gzip
+import os
+import random
+
+import numpy
+import numpy as np
+import pytest
+
+from helpers import load_golden
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def pop():
+    import __graft_entry__ as ge
+
+    ge.build()
+    from dna_factory_amd import population
+
+    return population
+
+
+def test_feeders_replay_the_reference_at_fixed_seeds(pop, tmp_path):
+    doc = load_golden("full_flow_120x400")
+    numpy.random.seed(doc["numpy_seed"])
+    random.seed(doc["python_random_seed"])
+    tb = pop.generate_snp_table(400, min_maf=0.01)
+    groups = pop.pick_deleterious(tb, os.path.join(REPO, "deleterious.yml"))
+    pop.write_deleterious_json(groups, tmp_path / "deleterious.json")
+    st = pop.build_samples(groups, 60, 60, 0.5, str(tmp_path))
+    # SNP list, in sorted order
+    for j, (sid, chrom, position, tuples) in enumerate(doc["snps"]):
+        assert (int(tb.snp_id[j]), tb.chrom[j].decode(), int(tb.position[j])) == (sid, chrom, position)
+        assert tb.ref[j].decode() == tuples[0][0] and tb.alt[j].decode() == tuples[1][0]
+        assert tb.cum[j, 0] == tuples[0][1] and tb.cum[j, 1] == tuples[1][1]
+    assert open(tmp_path / "deleterious.json").read() == doc["deleterious_json"]
+    assert open(tmp_path / "population.fam").read() == doc["population_fam"]
+    assert open(tmp_path / "pop_deleterious.txt").read() == doc["pop_deleterious_txt"]
+    hdr = pop.vcf_header(st.person_id).split("\n")
+    hdr[1] = "##filedate=FROZEN"
+    assert "\n".join(hdr) == doc["vcf_header"]
+    # the numpy stream is exactly where the reference's worker would start drawing
+    state = numpy.random.get_state()
+    assert list(state[1]) == doc["mt_state_key"] and state[2] == doc["mt_state_pos"]
+    # the sample table the worker sees
+    for i, (iid, sex, ctrl, carried) in enumerate(doc["samples"]):
+        assert int(st.person_id[i]) == iid
+        assert bool(st.flags[i] & 1) == (sex == 1) and bool(st.flags[i] & 2) == ctrl
+    per_sample = {}
+    for k, sid in enumerate(st.forced_ids):
+        for i in st.carrier_idx[int(st.carrier_off[k]): int(st.carrier_off[k + 1])]:
+            per_sample.setdefault(int(i), set()).add(int(sid))
+    for i, (_, _, ctrl, carried) in enumerate(doc["samples"]):
+        assert per_sample.get(i, set()) == set(carried or [])
+
+
+def test_snps_file_roundtrip_and_layout(pop, tmp_path):
+    numpy.random.seed(5)
+    random.seed(6)
+    tb = pop.generate_snp_table(300, min_maf=0.005)
+    path = tmp_path / "snps.json.gz"
+    pop.write_snps_file(tb, path)
+    lines = gzip.open(path, "rt").read().splitlines()
+    assert len(lines) == 300
+    # layout of str(SNPTuples), pop_factory.py:118-124
+    assert lines[0] == '{"id": %d, "chromosome": "%s", "position": %d, "tuples": {"%s": %r, "%s": 1.0}}' % (
+        tb.snp_id[0], tb.chrom[0].decode(), tb.position[0], tb.ref[0].decode(), float(tb.cum[0, 0]), tb.alt[0].decode())
+    back = pop.load_snps_file(path)
+    for col in ("snp_id", "chrom", "position", "ref", "alt", "n_alleles"):
+        assert np.array_equal(getattr(back, col), getattr(tb, col))
+    assert np.array_equal(back.cum[:, :2], tb.cum[:, :2])
+
+
+def test_sorted_by_chromosome_string_then_position(pop):
+    numpy.random.seed(9)
+    random.seed(9)
+    tb = pop.generate_snp_table(5000)
+    keys = [(c.decode(), int(p)) for c, p in zip(tb.chrom, tb.position)]
+    assert keys == sorted(keys)  # lexicographic on the chromosome string: 1,10,11,...,19,2,20,...
+    assert sorted(tb.snp_id) == list(range(1, 5001))
+    assert tb.cum[:, 0].min() >= 0.5 and np.all(tb.ref != tb.alt)
+
+
+def test_deleterious_json_key_quirk(pop, tmp_path):
+    g = pop.DeleteriousGroup("g-0", 2)
+    g.deleterious = {17: 0.5, 4: 0.5}
+    line = g.to_json()
+    assert line == '{"deleterious": {"17": 0.5, "4": 0.5}, "name": "g-0", "population_weight": 2}'
+    assert list(pop.DeleteriousGroup.from_json(line).deleterious) == [17, 4]
+    # reference behaviour (pop_factory.py:613-619): string keys, which never match an int SNP id
+    assert list(pop.DeleteriousGroup.from_json(line, int_keys=False).deleterious) == ["17", "4"]
+
+
+def test_bad_yaml_bounds_raise_like_the_reference(pop, tmp_path):
+    numpy.random.seed(1)
+    random.seed(1)
+    tb = pop.generate_snp_table(50)
+    cfg = tmp_path / "bad.yml"
+    cfg.write_text("g:\n  mutation_weights: [1]\n  population_weight: 1\n  max_minor_allele_freq: 0.7\n")
+    with pytest.raises(Exception, match="max_minor_allele_freq must be between 0 and 0.5"):
+        pop.pick_deleterious(tb, str(cfg))
+    cfg.write_text("g:\n  mutation_weights: [1]\n  population_weight: 1\n  max_minor_allele_freq: 0.0001\n")
+    with pytest.raises(Exception, match="No SNPs in list to choose from"):
+        pop.pick_deleterious(tb, str(cfg))
