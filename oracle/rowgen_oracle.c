@@ -317,3 +317,71 @@ int oracle_generate_threads(const oracle_snp* snps, uint64_t n_rows, uint64_t rn
     free(th); free(jobs);
     return rc;
 }
+
+/* Verify a buffer produced elsewhere (the HIP path) against this oracle, row range by row range on
+ * n_threads host threads (Philox mode).  text/row_off/packed are the buffers under test, laid out like
+ * oracle_generate's outputs.  *first_bad = index of the first differing row, or UINT64_MAX. */
+typedef struct {
+    const oracle_snp* snps; uint64_t row_lo, row_hi, rng_row0;
+    const uint8_t *sex, *is_control; const uint64_t* del_off; const int64_t* del_ids;
+    uint64_t S, seed; const char* text; const uint64_t* row_off; const uint32_t* packed;
+    uint64_t bad; int rc;
+} vf_job;
+
+static void* vf_worker(void* p)
+{
+    vf_job* j = (vf_job*)p;
+    const uint64_t chunk = 64, W = (j->S + 15) / 16;
+    uint64_t cap = chunk * (4 * j->S + 300) + 1024;
+    char* text = (char*)malloc(cap);
+    uint64_t* off = (uint64_t*)malloc(sizeof(uint64_t) * (chunk + 1));
+    uint32_t* pk = j->packed ? (uint32_t*)malloc(sizeof(uint32_t) * chunk * (W ? W : 1)) : NULL;
+    j->bad = UINT64_MAX; j->rc = 0;
+    if (!text || !off || (j->packed && !pk)) { j->rc = -3; free(text); free(off); free(pk); return NULL; }
+    for (uint64_t r = j->row_lo; r < j->row_hi && j->rc == 0 && j->bad == UINT64_MAX; r += chunk) {
+        uint64_t n = j->row_hi - r < chunk ? j->row_hi - r : chunk;
+        j->rc = oracle_generate(j->snps + r, n, j->rng_row0 + r, j->sex, j->is_control, j->del_off, j->del_ids,
+                                j->S, ORACLE_RNG_PHILOX, j->seed, NULL, 0, text, cap, off, pk);
+        if (j->rc) break;
+        for (uint64_t k = 0; k < n; ++k) {
+            uint64_t len = off[k + 1] - off[k];
+            if (j->row_off[r + k + 1] - j->row_off[r + k] != len ||
+                memcmp(j->text + j->row_off[r + k], text + off[k], len) != 0 ||
+                (pk && memcmp(j->packed + (r + k) * W, pk + k * W, W * sizeof(uint32_t)) != 0)) {
+                j->bad = r + k;
+                break;
+            }
+        }
+    }
+    free(text); free(off); free(pk);
+    return NULL;
+}
+
+int oracle_verify_threads(const oracle_snp* snps, uint64_t n_rows, uint64_t rng_row0,
+                          const uint8_t* sex, const uint8_t* is_control,
+                          const uint64_t* del_off, const int64_t* del_ids, uint64_t S,
+                          uint64_t seed, int n_threads, const char* text, const uint64_t* row_off,
+                          const uint32_t* packed, uint64_t* first_bad)
+{
+    if (n_threads < 1) n_threads = 1;
+    pthread_t* th = (pthread_t*)malloc(sizeof(pthread_t) * (size_t)n_threads);
+    vf_job* jobs = (vf_job*)malloc(sizeof(vf_job) * (size_t)n_threads);
+    if (!th || !jobs) { free(th); free(jobs); return -3; }
+    uint64_t per = (n_rows + (uint64_t)n_threads - 1) / (uint64_t)n_threads;
+    for (int t = 0; t < n_threads; ++t) {
+        uint64_t b = per * (uint64_t)t, e = b + per;
+        if (b > n_rows) b = n_rows;
+        if (e > n_rows) e = n_rows;
+        jobs[t] = (vf_job){snps, b, e, rng_row0, sex, is_control, del_off, del_ids, S, seed, text, row_off, packed, UINT64_MAX, 0};
+        pthread_create(&th[t], NULL, vf_worker, &jobs[t]);
+    }
+    int rc = 0; uint64_t bad = UINT64_MAX;
+    for (int t = 0; t < n_threads; ++t) {
+        pthread_join(th[t], NULL);
+        if (jobs[t].rc) rc = jobs[t].rc;
+        if (jobs[t].bad < bad) bad = jobs[t].bad;
+    }
+    if (first_bad) *first_bad = bad;
+    free(th); free(jobs);
+    return rc;
+}
