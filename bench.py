@@ -39,6 +39,9 @@ def parse_args():
     ap.add_argument("--table-seed", type=int, default=20261004, help="seed of the synthetic SNP / sample tables")
     ap.add_argument("--what", choices=["text+packed", "text", "packed"], default="text+packed")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target duration of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--bgzf-tiles", type=int, default=2,
+                    help="after the timed region, compress this many tiles with the on-GPU BGZF encoder and report "
+                         "its rate and ratio (0 = skip)")
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "pmc_traffic.json"),
                     help="HBM bytes per launch from a rocprofv3 --pmc run of this same command (optional)")
     return ap.parse_args()
@@ -252,6 +255,18 @@ def main():
                          "launches_timed": n_rec, "kernel": "rowgen_kernel",
                          "draws_per_s": 2.0 * S * a.tile_rows / mean_kernel_s},
         }
+        if a.bgzf_tiles > 0 and (what & capi.OUT_TEXT):
+            # the sink right after the path: BGZF members encoded on the GPU, outside the timed region
+            z_ms, z_in, z_out = 0.0, 0, 0
+            for t in range(a.bgzf_tiles):
+                gen.ctx.generate((t % n_tiles) * a.tile_rows, a.tile_rows, capi.OUT_TEXT)
+                z_out += gen.ctx.bgzf_compress(reuse_tables=t > 0)
+                z_in += gen.ctx.text_bytes((t % n_tiles) * a.tile_rows, a.tile_rows)
+                z_ms += gen.ctx.last_bgzf_ms()
+            out["bgzf"] = {"tiles": a.bgzf_tiles, "text_GB_per_s": z_in / (z_ms * 1e-3) / 1e9,
+                           "rows_per_s": a.bgzf_tiles * a.tile_rows / (z_ms * 1e-3), "ratio": z_in / z_out,
+                           "bytes_per_genotype": z_out / (a.bgzf_tiles * a.tile_rows * S),
+                           "kernel_ms_per_tile": z_ms / a.bgzf_tiles}
         if world == 1 and a.cpu_seconds > 0:
             out["cpu_baseline"] = cpu_baseline(tb, st, a.seed, a.cpu_seconds)
         else:

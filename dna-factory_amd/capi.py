@@ -23,6 +23,7 @@ CLASS_AUTOSOME, CLASS_X, CLASS_Y, CLASS_MT = 0, 1, 2, 3
 MAX_ALLELES = 4
 RNG_PHILOX, RNG_MT19937 = 0, 1
 OUT_TEXT, OUT_PACKED = 1, 2
+BGZF_REUSE_TABLES = 1
 
 # every symbol include/dnaf.h declares
 SYMBOLS = [
@@ -30,7 +31,8 @@ SYMBOLS = [
     "dnaf_set_forced", "dnaf_set_rng", "dnaf_set_snps", "dnaf_text_bytes", "dnaf_row_offsets", "dnaf_generate",
     "dnaf_reserve_output",
     "dnaf_sync", "dnaf_last_generate_ms", "dnaf_timing_begin", "dnaf_timing_end", "dnaf_read_text", "dnaf_read_packed", "dnaf_device_buffers",
-    "dnaf_format_prefixes",
+    "dnaf_format_prefixes", "dnaf_bgzf_compress", "dnaf_read_bgzf", "dnaf_last_bgzf_ms",
+    "dnaf_bgzf_tables_from_histogram",
 ]
 
 
@@ -82,6 +84,10 @@ def _load():
         "dnaf_read_packed": (ci, [vp, vp, u64, vp]),
         "dnaf_device_buffers": (ci, [vp, vp, vp, vp, vp]),
         "dnaf_format_prefixes": (ci, [u64, vp, u32, vp, vp, vp, u32, vp, u32, vp, u64, vp]),
+        "dnaf_bgzf_compress": (ci, [vp, u32, vp]),
+        "dnaf_read_bgzf": (ci, [vp, vp, u64, vp]),
+        "dnaf_last_bgzf_ms": (ci, [vp, vp]),
+        "dnaf_bgzf_tables_from_histogram": (ci, [vp, vp, u64, vp, u64, vp]),
     }
     for name in SYMBOLS:
         fn = getattr(lib, name)  # AttributeError here = the library does not export what the header declares
@@ -238,6 +244,23 @@ class Context:
         flat = buf.reshape(-1) if buf.size else np.empty(1, dtype=np.uint32)
         self._check(lib.dnaf_read_packed(self._h, ptr(flat), buf.size, ctypes.byref(got)))
         return buf
+
+    def bgzf_compress(self, reuse_tables=False):
+        """Compress the last generated text on the GPU; returns the number of BGZF bytes."""
+        n = ctypes.c_uint64(0)
+        self._check(lib.dnaf_bgzf_compress(self._h, BGZF_REUSE_TABLES if reuse_tables else 0, ctypes.byref(n)))
+        return n.value
+
+    def read_bgzf(self, n_bytes):
+        buf = np.empty(max(n_bytes, 1), dtype=np.uint8)
+        got = ctypes.c_uint64(0)
+        self._check(lib.dnaf_read_bgzf(self._h, ptr(buf), n_bytes, ctypes.byref(got)))
+        return buf[: got.value]
+
+    def last_bgzf_ms(self):
+        v = ctypes.c_float(0)
+        self._check(lib.dnaf_last_bgzf_ms(self._h, ctypes.byref(v)))
+        return v.value
 
     def device_buffers(self):
         t, p = ctypes.c_void_p(None), ctypes.c_void_p(None)

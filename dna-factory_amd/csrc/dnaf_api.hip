@@ -6,6 +6,7 @@
 // launches the kernel on the context's stream.
 #include "../../include/dnaf.h"
 #include "rowgen_kernels.hip.h"
+#include "bgzf_kernels.hip.h"
 
 #include <cmath>
 #include <cstdarg>
@@ -60,6 +61,19 @@ struct dnaf_ctx {
     uint64_t last_begin = 0, last_rows = 0;
     uint32_t last_what = 0;
     bool have_output = false;
+
+    // BGZF encoder
+    dnaf::BgzfTables* d_tables = nullptr;
+    bool have_tables = false;
+    uint32_t* d_hist = nullptr;
+    uint32_t* d_sizes = nullptr;
+    uint64_t* d_offsets = nullptr;
+    uint64_t blocks_cap = 0;
+    uint8_t* d_bgzf = nullptr;
+    uint64_t bgzf_cap = 0, bgzf_bytes = 0;
+    bool have_bgzf = false;
+    hipEvent_t zev[2] = {nullptr, nullptr};
+    float bgzf_ms = 0.f;
 
     // tuning
     uint32_t seg_iters = 32;
@@ -148,6 +162,12 @@ int dnaf_destroy(dnaf_ctx* c)
     dev_free(c->d_prefix);
     dev_free(c->d_text);
     dev_free(c->d_packed);
+    dev_free(c->d_tables);
+    dev_free(c->d_hist);
+    dev_free(c->d_sizes);
+    dev_free(c->d_offsets);
+    dev_free(c->d_bgzf);
+    for (hipEvent_t e : c->zev) if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : c->evs) (void)hipEventDestroy(e);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -388,6 +408,7 @@ int dnaf_generate(dnaf_ctx* c, uint64_t row_begin, uint64_t n_rows, uint32_t wha
     c->last_rows = n_rows;
     c->last_what = what;
     c->have_output = true;
+    c->have_bgzf = false;
     if (n_rows == 0) return DNAF_OK;
 
     GenParams p;
@@ -517,6 +538,130 @@ int dnaf_device_buffers(dnaf_ctx* c, void** d_text, uint64_t* text_bytes, void**
     if (text_bytes) *text_bytes = t ? c->h_text_off[(size_t)(c->last_begin + c->last_rows)] - c->h_text_off[(size_t)c->last_begin] : 0;
     if (d_packed) *d_packed = k ? c->d_packed : nullptr;
     if (packed_words) *packed_words = k ? c->last_rows * (uint64_t)c->W : 0;
+    return DNAF_OK;
+}
+
+// ---- on-GPU BGZF encoder: the sink right after the path (Bio.bgzf.BgzfWriter, pop_factory.py:403, :449) ----
+int dnaf_bgzf_compress(dnaf_ctx* c, uint32_t flags, uint64_t* n_bytes)
+{
+    if (!c) return DNAF_ERR_BAD_ARG;
+    if (!c->have_output || !(c->last_what & DNAF_OUT_TEXT)) return fail(c, DNAF_ERR_STATE, "dnaf_bgzf_compress: no text was generated");
+    if (flags & ~DNAF_BGZF_REUSE_TABLES) return fail(c, DNAF_ERR_BAD_ARG, "dnaf_bgzf_compress: flags = %u", flags);
+    HIP_TRY(c, hipSetDevice(c->device));
+    const uint64_t tbytes = c->h_text_off[(size_t)(c->last_begin + c->last_rows)] - c->h_text_off[(size_t)c->last_begin];
+    c->have_bgzf = false;
+    c->bgzf_bytes = 0;
+    c->bgzf_ms = 0.f;
+    if (n_bytes) *n_bytes = 0;
+    if (tbytes == 0) { c->have_bgzf = true; return DNAF_OK; }
+    const uint64_t nb64 = (tbytes + dnaf::BGZF_IN - 1) / dnaf::BGZF_IN;
+    if (nb64 > 0x7FFFFFFFull) return fail(c, DNAF_ERR_UNSUPPORTED, "dnaf_bgzf_compress: too many blocks");
+    const uint32_t nb = (uint32_t)nb64;
+    if (!c->zev[0]) { HIP_TRY(c, hipEventCreate(&c->zev[0])); HIP_TRY(c, hipEventCreate(&c->zev[1])); }
+    if (!c->d_tables) HIP_TRY(c, hipMalloc((void**)&c->d_tables, sizeof(dnaf::BgzfTables)));
+    if (!c->d_hist) HIP_TRY(c, hipMalloc((void**)&c->d_hist, 513 * sizeof(uint32_t)));
+    if (nb > c->blocks_cap) {
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        dev_free(c->d_sizes);
+        dev_free(c->d_offsets);
+        c->blocks_cap = 0;
+        HIP_TRY(c, hipMalloc((void**)&c->d_sizes, (uint64_t)nb * sizeof(uint32_t)));
+        HIP_TRY(c, hipMalloc((void**)&c->d_offsets, ((uint64_t)nb + 1) * sizeof(uint64_t)));
+        c->blocks_cap = nb;
+    }
+    dnaf::BgzfParams p;
+    p.text = c->d_text;
+    p.n_bytes = tbytes;
+    p.n_blocks = nb;
+    p.sample_step = nb > 512 ? nb / 512 : 1;
+    p.tables = c->d_tables;
+    p.hist = c->d_hist;
+    p.sizes = c->d_sizes;
+    p.offsets = c->d_offsets;
+    p.out = nullptr;
+    float ms_total = 0.f, ms = 0.f;
+    if (!(c->have_tables && (flags & DNAF_BGZF_REUSE_TABLES))) {
+        // 1. token histogram over a sample of blocks -> one Huffman table for the whole range
+        uint32_t h[513];
+        HIP_TRY(c, hipMemsetAsync(c->d_hist, 0, sizeof h, c->stream));
+        HIP_TRY(c, hipEventRecord(c->zev[0], c->stream));
+        hipLaunchKernelGGL(dnaf::bgzf_hist, dim3((nb + p.sample_step - 1) / p.sample_step), dim3(dnaf::BGZF_THREADS), 0, c->stream, p);
+        HIP_TRY(c, hipGetLastError());
+        HIP_TRY(c, hipEventRecord(c->zev[1], c->stream));
+        HIP_TRY(c, hipMemcpyAsync(h, c->d_hist, sizeof h, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        HIP_TRY(c, hipEventElapsedTime(&ms, c->zev[0], c->zev[1]));
+        ms_total += ms;
+        uint64_t lit[256], mat[256];
+        for (int i = 0; i < 256; ++i) { lit[i] = h[i]; mat[i] = h[256 + i]; }
+        static thread_local dnaf::BgzfTables tables;
+        dnaf::bgzf_build_tables(lit, mat, h[512], &tables);
+        HIP_TRY(c, hipMemcpy(c->d_tables, &tables, sizeof tables, hipMemcpyHostToDevice));
+        c->have_tables = true;
+    }
+    // 2. exact member sizes, 3. their exclusive scan
+    uint64_t total = 0;
+    HIP_TRY(c, hipEventRecord(c->zev[0], c->stream));
+    hipLaunchKernelGGL(dnaf::bgzf_size, dim3(nb), dim3(dnaf::BGZF_THREADS), 0, c->stream, p);
+    HIP_TRY(c, hipGetLastError());
+    hipLaunchKernelGGL(dnaf::bgzf_scan, dim3(1), dim3(1024), 0, c->stream, (const uint32_t*)c->d_sizes, nb, c->d_offsets);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipEventRecord(c->zev[1], c->stream));
+    HIP_TRY(c, hipMemcpyAsync(&total, c->d_offsets + nb, sizeof total, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipEventElapsedTime(&ms, c->zev[0], c->zev[1]));
+    ms_total += ms;
+    if (total > c->bgzf_cap) {
+        dev_free(c->d_bgzf);
+        c->bgzf_cap = 0;
+        const uint64_t want = total + total / 4 + 65536; // headroom: later tiles compress to similar sizes
+        HIP_TRY(c, hipMalloc((void**)&c->d_bgzf, want));
+        c->bgzf_cap = want;
+    }
+    // 4. encode every member at its offset
+    p.out = c->d_bgzf;
+    HIP_TRY(c, hipEventRecord(c->zev[0], c->stream));
+    hipLaunchKernelGGL(dnaf::bgzf_encode, dim3(nb), dim3(dnaf::BGZF_THREADS), 0, c->stream, p);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipEventRecord(c->zev[1], c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipEventElapsedTime(&ms, c->zev[0], c->zev[1]));
+    ms_total += ms;
+    c->bgzf_ms = ms_total;
+    c->bgzf_bytes = total;
+    c->have_bgzf = true;
+    if (n_bytes) *n_bytes = total;
+    return DNAF_OK;
+}
+
+int dnaf_read_bgzf(dnaf_ctx* c, void* dst, uint64_t dst_cap, uint64_t* n_bytes)
+{
+    if (!c) return DNAF_ERR_BAD_ARG;
+    if (!c->have_bgzf) return fail(c, DNAF_ERR_STATE, "dnaf_read_bgzf: nothing was compressed");
+    if (n_bytes) *n_bytes = c->bgzf_bytes;
+    if (c->bgzf_bytes > dst_cap) return fail(c, DNAF_ERR_BAD_ARG, "dnaf_read_bgzf: need %llu bytes, have %llu", (unsigned long long)c->bgzf_bytes, (unsigned long long)dst_cap);
+    if (c->bgzf_bytes && !dst) return fail(c, DNAF_ERR_BAD_ARG, "dnaf_read_bgzf: dst is NULL");
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (c->bgzf_bytes) HIP_TRY(c, hipMemcpyAsync(dst, c->d_bgzf, c->bgzf_bytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return DNAF_OK;
+}
+
+int dnaf_last_bgzf_ms(dnaf_ctx* c, float* ms)
+{
+    if (!c || !ms) return DNAF_ERR_BAD_ARG;
+    if (!c->have_bgzf) return fail(c, DNAF_ERR_STATE, "dnaf_last_bgzf_ms: nothing was compressed");
+    *ms = c->bgzf_ms;
+    return DNAF_OK;
+}
+
+// Host-only: the tables the encoder would use for a given token histogram (lets CPU tests inflate a
+// stream assembled from them).  out must hold sizeof(BgzfTables) bytes; *size receives that size.
+int dnaf_bgzf_tables_from_histogram(const uint64_t* lit_hist, const uint64_t* match_hist, uint64_t n_eob, void* out, uint64_t out_cap, uint64_t* size)
+{
+    if (size) *size = sizeof(dnaf::BgzfTables);
+    if (!lit_hist || !match_hist || !out || out_cap < sizeof(dnaf::BgzfTables)) return DNAF_ERR_BAD_ARG;
+    dnaf::bgzf_build_tables(lit_hist, match_hist, n_eob, (dnaf::BgzfTables*)out);
     return DNAF_OK;
 }
 

@@ -139,6 +139,21 @@ int dnaf_read_packed(dnaf_ctx* ctx, uint32_t* dst, uint64_t dst_cap_words, uint6
  * the GPU (valid until the next dnaf_generate / dnaf_destroy). */
 int dnaf_device_buffers(dnaf_ctx* ctx, void** d_text, uint64_t* text_bytes, void** d_packed, uint64_t* packed_words);
 
+/* On-GPU BGZF encoder -- the sink right after the path (the reference pushes every line through
+ * Bio.bgzf.BgzfWriter, pop_factory.py:403, :449).  Compresses the text of the last dnaf_generate
+ * into a sequence of BGZF members (gzip members with the BC extra field, <= 64 KiB each, no EOF
+ * block) in device memory; any gzip reader returns the input bytes.  flags: DNAF_BGZF_REUSE_TABLES
+ * keeps the Huffman tables of the previous call instead of sampling the new text.  Synchronises. */
+#define DNAF_BGZF_REUSE_TABLES 1u
+int dnaf_bgzf_compress(dnaf_ctx* ctx, uint32_t flags, uint64_t* n_bytes);
+int dnaf_read_bgzf(dnaf_ctx* ctx, void* dst, uint64_t dst_cap, uint64_t* n_bytes);
+/* Summed device time of the encoder's kernels in the last dnaf_bgzf_compress (HIP events). */
+int dnaf_last_bgzf_ms(dnaf_ctx* ctx, float* ms);
+/* Host-only helper: the encoder's code tables for a token histogram (256 literal counts, 256 counts
+ * of match lengths 3..258, end-of-block count); out receives an opaque table blob. */
+int dnaf_bgzf_tables_from_histogram(const uint64_t* lit_hist, const uint64_t* match_hist, uint64_t n_eob, void* out,
+                                    uint64_t out_cap, uint64_t* size);
+
 /* Host helper: format the fixed columns of each row exactly like
  * pop_factory.py:503-507 ("%s\t%i\trs%s\t%s\t%s\t40\tPASS\t.\tGT\t").
  * chrom/ref/alt are fixed-width, NUL-padded byte fields (numpy 'S<w>' arrays).
