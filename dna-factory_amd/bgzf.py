@@ -71,6 +71,13 @@ class BgzfWriter:
         if pos < len(mv):
             self._buf += mv[pos:]
 
+    def write_members(self, blob):
+        """Append BGZF members that were produced elsewhere (the GPU encoder), after everything written so far."""
+        self.flush()
+        mv = memoryview(blob).cast("B")
+        self._f.write(mv)
+        self.bytes_out += len(mv)
+
     def flush(self):
         if self._buf:
             self._pending.append(self._pool.submit(compress_block, bytes(self._buf), self._level))

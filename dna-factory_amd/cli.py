@@ -3,7 +3,7 @@ and its output directory layout, with the VCF body produced 
 
 Reference flags keep their names, dests and defaults (pinned by the reference's own
 test/unit/pop_factory_test.py:80-104).  Additive flags: --seed, --rng, --devices, --tile-rows, --threads,
---compat-deleterious-file-bug.
+--host-bgzf, --compat-deleterious-file-bug.
 """
 import argparse
 import os
@@ -51,6 +51,9 @@ def parse_cmd_args(args):
     p.add_argument("--devices", type=str, default="0", help="comma-separated GPU ids; SNP ranges are sharded over them")
     p.add_argument("--tile-rows", type=int, default=0, help="SNP rows generated per kernel launch (0 = auto)")
     p.add_argument("--threads", type=int, default=0, help="BGZF compression threads per shard (0 = auto)")
+    p.add_argument("--host-bgzf", action="store_true",
+                   help="compress on the host with zlib at level -z (like the reference) instead of the on-GPU BGZF "
+                        "encoder, which ignores -z")
     p.add_argument("--compat-deleterious-file-bug", action="store_true",
                    help="keep the reference's behaviour for --deleterious_file: ids stay strings, so nothing is forced")
     return p.parse_args(args)
@@ -61,8 +64,10 @@ def _auto_tile_rows(n_samples, n_rows):
     return max(1, min(max(n_rows, 1), (512 << 20) // per_row))
 
 
-def _generate_shard(device, seed, rng, st, tb, row_lo, row_hi, tile_rows, sink, progress):
-    """Rows [row_lo, row_hi) of the table on one GPU -> sink.write(bytes), in order."""
+def _generate_shard(device, seed, rng, st, tb, row_lo, row_hi, tile_rows, sink, progress, host_bgzf):
+    """Rows [row_lo, row_hi) of the table on one GPU -> the BGZF sink, in order.  By default the text is
+    compressed on the GPU and only BGZF members cross PCIe; with host_bgzf the text is copied out and
+    compressed by the sink's zlib workers."""
     from .rowgen import RowGenerator
 
     with RowGenerator(device=device, seed=seed, rng=rng) as gen:
@@ -71,12 +76,16 @@ def _generate_shard(device, seed, rng, st, tb, row_lo, row_hi, tile_rows, sink, 
         n = row_hi - row_lo
         for b in range(0, n, tile_rows):
             m = min(tile_rows, n - b)
-            text, _, _ = gen.generate(b, m, text=True, packed=False)
-            sink.write(text)
+            if host_bgzf:
+                text, _, _ = gen.generate(b, m, text=True, packed=False)
+                sink.write(text)
+            else:
+                blob, _ = gen.generate_bgzf(b, m, reuse_tables=b > 0)
+                sink.write_members(blob)
             progress(m)
 
 
-def write_vcf(path, header, st, tb, seed, rng, devices, compresslevel, tile_rows=0, threads=0):
+def write_vcf(path, header, st, tb, seed, rng, devices, compresslevel, tile_rows=0, threads=0, host_bgzf=False):
     """population.vcf.gz = header + one body line per SNP (output_vcf_population, pop_factory.py:385-415).
     With several devices each GPU writes its contiguous SNP range to its own BGZF shard; shards are then
     concatenated (BGZF members are independent), ending with a single EOF block."""
@@ -100,7 +109,7 @@ def write_vcf(path, header, st, tb, seed, rng, devices, compresslevel, tile_rows
     if len(devices) == 1:
         with bgzf.BgzfWriter(path, compresslevel=compresslevel, threads=threads) as f:
             f.write(header)
-            _generate_shard(devices[0], seed, rng, st, tb, 0, n, tile_rows, f, progress)
+            _generate_shard(devices[0], seed, rng, st, tb, 0, n, tile_rows, f, progress, host_bgzf)
     else:
         from .sharding import shard_bounds
 
@@ -115,7 +124,7 @@ def write_vcf(path, header, st, tb, seed, rng, devices, compresslevel, tile_rows
                     w = bgzf.BgzfWriter(fileobj=_NoClose(raw), compresslevel=compresslevel, threads=threads)
                     if g == 0:
                         w.write(header)
-                    _generate_shard(devices[g], seed, rng, st, tb, bounds[g], bounds[g + 1], tile_rows, w, progress)
+                    _generate_shard(devices[g], seed, rng, st, tb, bounds[g], bounds[g + 1], tile_rows, w, progress, host_bgzf)
                     w.flush()  # no EOF block inside a shard
                     w.close_pool()
             except BaseException as e:  # surfaced in the parent, never swallowed
@@ -198,7 +207,7 @@ def generate_population(args):
     header = pop.vcf_header(st.person_id)
     devices = [int(d) for d in args.devices.split(",") if d != ""]
     write_vcf(outdir + "population.vcf.gz", header, st, tb, seed, args.rng, devices, args.compression_level,
-              tile_rows=args.tile_rows, threads=args.threads)
+              tile_rows=args.tile_rows, threads=args.threads, host_bgzf=args.host_bgzf)
     print("Finished Generating Population in %0.4f secs." % (time.time() - t_start), flush=True)
     return outdir
 

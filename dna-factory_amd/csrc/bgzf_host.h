@@ -17,8 +17,8 @@
 
 namespace dnaf {
 
-constexpr uint32_t BGZF_IN = 64512;   // input bytes per BGZF block = 256 threads x 252 bytes
-constexpr uint32_t BGZF_CHUNK = 252;  // bytes tokenised by one thread
+constexpr uint32_t BGZF_IN = 64512;   // input bytes per BGZF block = 1008 threads x 64 bytes
+constexpr uint32_t BGZF_CHUNK = 64;   // bytes tokenised by one thread
 constexpr uint32_t BGZF_NLIT = 286;   // literal/length symbols 0..285
 constexpr uint32_t BGZF_HDR_WORDS = 48;
 
@@ -31,7 +31,7 @@ struct BgzfTables {
     uint32_t hdr_nbits;           // bits of the block header (BFINAL, BTYPE, code descriptions)
     uint32_t hdr[BGZF_HDR_WORDS]; // header bits, LSB first
     uint32_t crc_table[4][256];   // slicing-by-4 CRC-32 tables
-    uint32_t crc_shift_chunk[256]; // x^(8*252*j) mod P, j = 0..255 (zlib's reflected convention)
+    uint32_t crc_shift_chunk[1024]; // x^(8*64*j) mod P, j = 0..1023 (zlib's reflected convention)
     uint32_t crc_shift_byte[256];  // x^(8*r) mod P, r = 0..255
 };
 
@@ -194,10 +194,8 @@ inline void bgzf_build_tables(const uint64_t* lit_hist, const uint64_t* match_hi
     for (uint32_t i = 0; i < 256; ++i)
         for (int k = 1; k < 4; ++k)
             t->crc_table[k][i] = (t->crc_table[k - 1][i] >> 8) ^ t->crc_table[0][t->crc_table[k - 1][i] & 0xFFu];
-    for (uint32_t j = 0; j < 256; ++j) {
-        t->crc_shift_chunk[j] = crc_x8n((uint64_t)BGZF_CHUNK * j);
-        t->crc_shift_byte[j] = crc_x8n(j);
-    }
+    for (uint32_t j = 0; j < 1024; ++j) t->crc_shift_chunk[j] = crc_x8n((uint64_t)BGZF_CHUNK * j);
+    for (uint32_t j = 0; j < 256; ++j) t->crc_shift_byte[j] = crc_x8n(j);
 }
 
 } // namespace dnaf

@@ -1,18 +1,21 @@
 // bgzf_kernels.hip.h -- GPU BGZF (blocked gzip) encoder for the VCF text stream (gfx950).
 //
-// One 256-thread workgroup encodes one BGZF member from 64,512 input bytes; a thread owns a
-// 252-byte chunk.  Tokens are literals and matches at distance 4 only: byte i matches when it equals
-// byte i-4 of the same block (GT cells repeat with period 4; haploid cells with period 2).  Runs of
-// matching bytes never cross a thread's chunk, so tokenisation needs only the dword in front of the
-// chunk, and a run is a single match token (<= 252 <= 258).
+// One 1024-thread workgroup encodes one BGZF member from 64,512 input bytes; 1008 of its threads own
+// a 64-byte chunk each.  Tokens are literals and matches at distance 4 only: byte i matches when it
+// equals byte i-4 of the same block (GT cells repeat with period 4; haploid cells with period 2).
+// Runs of matching bytes never cross a thread's chunk, so a chunk's 64 match bits live in one 64-bit
+// register and tokenisation is bit arithmetic: runs of >= 3 ones are matches, everything else is a
+// literal.  The block is staged in LDS once (coalesced 16-byte global loads) in a padded image that
+// makes the per-thread chunk reads bank-conflict free; token walks fetch literal bytes and code-table
+// entries four tokens at a time so their LDS latencies overlap.
 //
 //   bgzf_hist    token histogram over a sample of blocks          -> Huffman tables (host, bgzf_host.h)
 //   bgzf_size    exact compressed size of every block             -> exclusive scan -> output offsets
 //   bgzf_encode  header + deflate bits (assembled in LDS) + CRC-32 + ISIZE, written at the block's offset
 //
 // A block whose deflate body would not fit the LDS buffer (or not beat a stored block) is emitted as
-// a stored block.  Output is checked by inflating it on the host (tests/test_bgzf_gpu.py): any
-// conforming gzip reader must return the input bytes and accept CRC-32 / ISIZE.
+// a stored block.  Output is checked by inflating it on the host (tests/test_bgzf.py): any conforming
+// gzip reader must return the input bytes and accept CRC-32 / ISIZE.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -21,13 +24,17 @@
 
 namespace dnaf {
 
-constexpr uint32_t BGZF_THREADS = 256;
-constexpr uint32_t BGZF_LDS_OUT = 32768;              // bytes of LDS for one block's deflate body
-constexpr uint32_t BGZF_MASK_WORDS = 9;               // 252 match bits + a zero sentinel word
-constexpr uint32_t BGZF_MEMBER_OVERHEAD = 18 + 8;     // gzip header with BC field + CRC32 + ISIZE
+constexpr uint32_t BGZF_THREADS = 1024;
+constexpr uint32_t BGZF_WAVES = BGZF_THREADS / 64;
+constexpr uint32_t BGZF_ACTIVE = BGZF_IN / BGZF_CHUNK; // 1008 threads own a chunk
+constexpr uint32_t BGZF_CHUNK_WORDS = BGZF_CHUNK / 4;  // 16
+constexpr uint32_t BGZF_LDS_OUT = 32768;               // bytes of LDS for one block's deflate body
+constexpr uint32_t BGZF_MEMBER_OVERHEAD = 18 + 8;      // gzip header with BC field + CRC32 + ISIZE
+static_assert(BGZF_CHUNK == 64, "a chunk's match bits must fit one 64-bit register");
+static_assert(BGZF_ACTIVE * BGZF_CHUNK == BGZF_IN && BGZF_ACTIVE <= BGZF_THREADS, "chunking must tile the block");
 
 struct BgzfParams {
-    const uint8_t* text;     // input stream
+    const uint8_t* text;     // input stream (16-byte aligned base, readable 64 bytes past n_bytes)
     uint64_t n_bytes;        // its length
     uint32_t n_blocks;       // ceil(n_bytes / BGZF_IN)
     uint32_t sample_step;    // bgzf_hist: encode every sample_step-th block
@@ -38,113 +45,137 @@ struct BgzfParams {
     uint8_t* out;
 };
 
-__device__ __forceinline__ uint32_t load_u32(const uint8_t* p)
+__device__ __forceinline__ uint32_t block_len(const BgzfParams& p, uint32_t b)
 {
-    uint32_t v;
-    __builtin_memcpy(&v, p, 4);
-    return v;
+    const uint64_t left = p.n_bytes - (uint64_t)b * BGZF_IN;
+    return left < BGZF_IN ? (uint32_t)left : BGZF_IN;
 }
 
-// Match bits of one thread's chunk -> mk[0..8] in LDS (bit p = byte c0+p equals byte c0+p-4).
-// Optionally accumulates the chunk's CRC-32 (standard: init ~0, final xor ~0).
+// LDS image of the block: dword i lives at index i + i/16, i.e. every 64-byte chunk is followed by one
+// pad dword.  Thread t's k-th dword is at 17 t + k: bank (17 t + k) mod 32, distinct over 32 lanes.
+constexpr uint32_t BGZF_LDS_IN_WORDS = BGZF_IN / 4 + BGZF_ACTIVE + 8;
+__device__ __forceinline__ uint32_t lds_word(uint32_t i) { return i + (i >> 4); }
+
+// Copy the block into LDS: coalesced 16-byte global loads (BGZF_IN is a multiple of 16 and so is every
+// block's start offset in the stream), dword stores into the padded image.
+__device__ __forceinline__ void stage_block(const uint8_t* blk, uint32_t N, uint32_t* in_lds)
+{
+    const uint4* src = reinterpret_cast<const uint4*>(blk);
+    for (uint32_t i = threadIdx.x; i < (N + 15u) / 16u; i += BGZF_THREADS) {
+        const uint4 v = src[i];
+        const uint32_t w = lds_word(4u * i); // the 4 dwords of a 16-byte group never straddle a chunk
+        in_lds[w] = v.x; in_lds[w + 1] = v.y; in_lds[w + 2] = v.z; in_lds[w + 3] = v.w;
+    }
+}
+
+// The tokens of one chunk as bit sets (bit p = byte p of the chunk).
+struct ChunkTokens {
+    uint64_t lit;   // bytes emitted as literals
+    uint64_t mstart; // first byte of each match
+    uint64_t mend;   // last byte of each match (k-th end belongs to k-th start)
+};
+
+// Match bits of one thread's chunk (bit p = byte c0+p equals byte c0+p-4) from the staged block, then
+// the token sets.  Optionally accumulates the chunk's CRC-32 (standard: init ~0, final xor ~0).
 template <bool WITH_CRC>
-__device__ __forceinline__ uint32_t chunk_mask(const uint8_t* blk, uint32_t c0, uint32_t len, uint32_t* mk,
-                                               const uint32_t (*crc_tab)[256])
+__device__ __forceinline__ ChunkTokens chunk_tokens(const uint32_t* in_lds, uint32_t tid, uint32_t len,
+                                                    const uint32_t (*crc_tab)[256], uint32_t* crc_out)
 {
     uint32_t crc = 0xFFFFFFFFu;
-    uint32_t prev = c0 ? load_u32(blk + c0 - 4) : 0u;
-    uint32_t word = 0;
+    const uint32_t* d = in_lds + tid * (BGZF_CHUNK_WORDS + 1u);
+    uint32_t prev = tid ? d[-2] : 0u; // last dword of the previous chunk (d[-1] is that chunk's pad)
+    uint64_t M = 0;
 #pragma unroll
-    for (uint32_t k = 0; k < BGZF_CHUNK / 4; ++k) {
-        uint32_t nib = 0;
-        if (4u * k < len) { // bytes past the end of the stream are never read beyond the buffer's slack
-            const uint32_t cur = load_u32(blk + c0 + 4u * k);
+    for (uint32_t k = 0; k < BGZF_CHUNK_WORDS; ++k) {
+        if (4u * k < len) {
+            const uint32_t cur = d[k];
             const uint32_t x = cur ^ prev;
             const uint32_t y = ((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x; // bit 7 of each byte: byte != 0
             const uint32_t e = ~y & 0x80808080u;
-            nib = ((e >> 7) & 1u) | ((e >> 14) & 2u) | ((e >> 21) & 4u) | ((e >> 28) & 8u);
+            const uint32_t nib = ((e >> 7) & 1u) | ((e >> 14) & 2u) | ((e >> 21) & 4u) | ((e >> 28) & 8u);
+            M |= (uint64_t)nib << (4u * k);
             if (WITH_CRC && 4u * k + 4u <= len) {
                 const uint32_t v = crc ^ cur;
                 crc = crc_tab[3][v & 0xFFu] ^ crc_tab[2][(v >> 8) & 0xFFu] ^ crc_tab[1][(v >> 16) & 0xFFu] ^ crc_tab[0][v >> 24];
             }
             prev = cur;
         }
-        if (c0 == 0 && k == 0) nib = 0; // no history before the block's first 4 bytes
-        word |= nib << (4u * (k & 7u));
-        if ((k & 7u) == 7u || k == BGZF_CHUNK / 4 - 1) {
-            mk[k >> 3] = word;
-            word = 0;
-        }
     }
-    mk[8] = 0;
-    // clear bits at and past `len` (only the stream's last block has short chunks)
-    if (len < BGZF_CHUNK) {
-        for (uint32_t w = len >> 5; w < 8; ++w) {
-            const uint32_t keep = (w == (len >> 5)) ? ((1u << (len & 31u)) - 1u) : 0u;
-            mk[w] &= keep;
+    if (tid == 0) M &= ~0xFull; // no history before the block's first 4 bytes
+    const uint64_t valid = len >= 64u ? ~0ull : ((1ull << len) - 1ull);
+    M &= valid; // only the stream's last block has a short chunk
+    if (WITH_CRC) {
+        if (len & 3u) {
+            const uint8_t* bytes = reinterpret_cast<const uint8_t*>(d);
+            for (uint32_t i = len & ~3u; i < len; ++i) crc = crc_tab[0][(crc ^ bytes[i]) & 0xFFu] ^ (crc >> 8);
         }
-        if (WITH_CRC)
-            for (uint32_t i = len & ~3u; i < len; ++i) crc = crc_tab[0][(crc ^ blk[c0 + i]) & 0xFFu] ^ (crc >> 8);
+        *crc_out = ~crc;
     }
-    return ~crc;
+    // runs of ones shorter than 3 cannot be matches (deflate's minimum match length)
+    const uint64_t up = M << 1, dn = M >> 1;
+    const uint64_t r1 = M & ~up & ~dn;             // isolated ones
+    const uint64_t a = M & dn & ~(M >> 2) & ~up;   // low bit of a run of exactly two
+    const uint64_t m3 = M & ~(r1 | a | (a << 1));  // ones in runs of >= 3
+    ChunkTokens t;
+    t.lit = ~m3 & valid;
+    t.mstart = m3 & ~(m3 << 1);
+    t.mend = m3 & ~(m3 >> 1);
+    return t;
 }
 
-// Visit the tokens of a chunk in order: v.literal(byte offset in chunk) / v.match(length).
-template <class V>
-__device__ __forceinline__ void walk_tokens(const uint32_t* mk, uint32_t len, V& v)
+// Visit the chunk's tokens in byte order, four at a time: positions come from registers, so the four
+// literal-byte reads, then the four table reads, are issued back to back.  sink(entry) receives
+// (bits << 5 | nbits) from the code table tab[0..255] = literals, tab[256 + L - 3] = match length L.
+template <class Sink>
+__device__ __forceinline__ void walk_tokens(ChunkTokens t, const uint8_t* chunk, const uint32_t* tab, Sink& sink)
 {
-    uint32_t pos = 0;
-    while (pos < len) {
-        const uint32_t wi = pos >> 5, sh = pos & 31u;
-        const uint32_t w = (uint32_t)((((uint64_t)mk[wi + 1] << 32) | mk[wi]) >> sh); // 32 valid bits from pos
-        if (w & 1u) {
-            uint32_t run = (~w) ? (uint32_t)__builtin_ctz(~w) : 32u;
-            while ((run & 31u) == 0u && pos + run < len) { // the run fills the window: keep counting
-                const uint32_t p2 = pos + run;
-                const uint32_t w2 = (uint32_t)((((uint64_t)mk[(p2 >> 5) + 1] << 32) | mk[p2 >> 5]) >> (p2 & 31u));
-                const uint32_t c = (~w2) ? (uint32_t)__builtin_ctz(~w2) : 32u;
-                run += c;
-                if (c < 32u) break;
+    uint64_t T = t.lit | t.mstart, E = t.mend;
+    while (T) {
+        uint32_t idx[4];
+        bool has[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            has[u] = T != 0;
+            const uint32_t p = has[u] ? (uint32_t)__builtin_ctzll(T) : 0u;
+            T &= T - 1; // stays 0 once empty
+            const bool is_match = has[u] && ((t.mstart >> p) & 1ull);
+            uint32_t L = 3;
+            if (is_match) {
+                L = (uint32_t)__builtin_ctzll(E) - p + 1u;
+                E &= E - 1;
             }
-            if (run > len - pos) run = len - pos;
-            if (run >= 3u) v.match(run);
-            else
-                for (uint32_t j = 0; j < run; ++j) v.literal(pos + j);
-            pos += run;
-        } else {
-            uint32_t z = w ? (uint32_t)__builtin_ctz(w) : 32u;
-            if (z > len - pos) z = len - pos;
-            for (uint32_t j = 0; j < z; ++j) v.literal(pos + j);
-            pos += z;
+            idx[u] = is_match ? 256u + L - 3u : p; // for literals: resolved to the byte value below
+            has[u] = has[u];
+            if (!is_match) idx[u] |= 0x80000000u;
         }
+        uint32_t byte[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) byte[u] = chunk[idx[u] & 63u];
+        uint32_t entry[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) entry[u] = tab[(idx[u] >> 31) ? byte[u] : idx[u]];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (has[u]) sink.token(entry[u], (idx[u] >> 31) ? byte[u] : idx[u]);
     }
 }
 
-struct CountVisitor {
-    const uint8_t* chunk;
-    const uint32_t* lit_tab;
-    const uint32_t* match_tab;
+struct CountSink {
     uint32_t bits;
-    __device__ __forceinline__ void literal(uint32_t p) { bits += lit_tab[chunk[p]] & 31u; }
-    __device__ __forceinline__ void match(uint32_t L) { bits += match_tab[L - 3u] & 31u; }
+    __device__ __forceinline__ void token(uint32_t entry, uint32_t) { bits += entry & 31u; }
 };
 
-struct HistVisitor {
-    const uint8_t* chunk;
-    uint32_t* h; // LDS histogram
-    __device__ __forceinline__ void literal(uint32_t p) { atomicAdd(&h[chunk[p]], 1u); }
-    __device__ __forceinline__ void match(uint32_t L) { atomicAdd(&h[256u + L - 3u], 1u); }
+struct HistSink {
+    uint32_t* h; // LDS histogram [512]: literal byte, or 256 + L - 3
+    __device__ __forceinline__ void token(uint32_t, uint32_t symbol) { atomicAdd(&h[symbol], 1u); }
 };
 
-struct EmitVisitor {
-    const uint8_t* chunk;
-    const uint32_t* lit_tab;
-    const uint32_t* match_tab;
-    uint32_t* out;      // LDS bit buffer (zero-initialised), written with atomic OR
-    uint64_t acc;       // pending bits, LSB first
-    uint32_t nacc;      // number of pending bits
-    uint32_t word;      // index of the LDS word the pending bits start in
-    __device__ __forceinline__ void put(uint32_t entry)
+struct EmitSink {
+    uint32_t* out; // LDS bit buffer (zero-initialised), written with atomic OR
+    uint64_t acc;  // pending bits, LSB first
+    uint32_t nacc; // number of pending bits
+    uint32_t word; // index of the LDS word the pending bits start in
+    __device__ __forceinline__ void token(uint32_t entry, uint32_t)
     {
         acc |= (uint64_t)(entry >> 5) << nacc;
         nacc += entry & 31u;
@@ -155,23 +186,14 @@ struct EmitVisitor {
             nacc -= 32u;
         }
     }
-    __device__ __forceinline__ void literal(uint32_t p) { put(lit_tab[chunk[p]]); }
-    __device__ __forceinline__ void match(uint32_t L) { put(match_tab[L - 3u]); }
     __device__ __forceinline__ void flush()
     {
         if (nacc) atomicOr(&out[word], (uint32_t)acc);
     }
 };
 
-__device__ __forceinline__ uint32_t block_len(const BgzfParams& p, uint32_t b)
-{
-    const uint64_t start = (uint64_t)b * BGZF_IN;
-    const uint64_t left = p.n_bytes - start;
-    return left < BGZF_IN ? (uint32_t)left : BGZF_IN;
-}
-
-// exclusive scan of one value per thread over the 256-thread workgroup; returns the thread's prefix and
-// the total in *total.  scratch: 8 words of LDS.
+// exclusive scan of one value per thread over the workgroup; returns the thread's prefix and the
+// total in *total.  scratch: BGZF_WAVES words of LDS.
 __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* scratch, uint32_t* total)
 {
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
@@ -181,63 +203,71 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* s
         const uint32_t n = __shfl_up(incl, d, 64);
         if ((int)lane >= d) incl += n;
     }
+    __syncthreads();
     if (lane == 63u) scratch[wave] = incl;
     __syncthreads();
-    uint32_t base = 0;
-    for (uint32_t w = 0; w < wave; ++w) base += scratch[w];
-    *total = scratch[0] + scratch[1] + scratch[2] + scratch[3];
-    __syncthreads();
+    uint32_t base = 0, tot = 0;
+    for (uint32_t w = 0; w < BGZF_WAVES; ++w) {
+        const uint32_t s = scratch[w];
+        if (w < wave) base += s;
+        tot += s;
+    }
+    *total = tot;
     return base + incl - v;
 }
 
 __global__ __launch_bounds__(BGZF_THREADS) void bgzf_hist(const BgzfParams p)
 {
-    __shared__ uint32_t mask[BGZF_THREADS * BGZF_MASK_WORDS];
+    __shared__ uint32_t in_lds[BGZF_LDS_IN_WORDS];
+    __shared__ uint32_t tab[512];
     __shared__ uint32_t h[513];
-    const uint32_t b = blockIdx.x * p.sample_step;
+    const uint32_t b = blockIdx.x * p.sample_step, tid = threadIdx.x;
     if (b >= p.n_blocks) return;
-    for (uint32_t i = threadIdx.x; i < 513; i += BGZF_THREADS) h[i] = 0;
-    __syncthreads();
+    if (tid < 513) h[tid] = 0;
+    if (tid < 512) tab[tid] = 0; // entries are not needed for counting symbols
     const uint32_t N = block_len(p, b);
-    const uint8_t* blk = p.text + (uint64_t)b * BGZF_IN;
-    const uint32_t c0 = threadIdx.x * BGZF_CHUNK;
+    stage_block(p.text + (uint64_t)b * BGZF_IN, N, in_lds);
+    __syncthreads();
+    const uint32_t c0 = tid * BGZF_CHUNK;
     if (c0 < N) {
         const uint32_t len = min(BGZF_CHUNK, N - c0);
-        uint32_t* mk = mask + threadIdx.x * BGZF_MASK_WORDS;
-        chunk_mask<false>(blk, c0, len, mk, nullptr);
-        HistVisitor v{blk + c0, h};
-        walk_tokens(mk, len, v);
+        const ChunkTokens t = chunk_tokens<false>(in_lds, tid, len, nullptr, nullptr);
+        HistSink s{h};
+        walk_tokens(t, reinterpret_cast<const uint8_t*>(in_lds + tid * (BGZF_CHUNK_WORDS + 1u)), tab, s);
     }
-    if (threadIdx.x == 0) atomicAdd(&h[512], 1u);
+    if (tid == 0) atomicAdd(&h[512], 1u);
     __syncthreads();
-    for (uint32_t i = threadIdx.x; i < 513; i += BGZF_THREADS)
-        if (h[i]) atomicAdd(&p.hist[i], h[i]);
+    if (tid < 513 && h[tid]) atomicAdd(&p.hist[tid], h[tid]);
+}
+
+__device__ __forceinline__ void load_code_table(const BgzfParams& p, uint32_t* tab)
+{
+    if (threadIdx.x < 256) tab[threadIdx.x] = p.tables->lit[threadIdx.x];
+    else if (threadIdx.x < 512) tab[threadIdx.x] = p.tables->match[threadIdx.x - 256];
 }
 
 __global__ __launch_bounds__(BGZF_THREADS) void bgzf_size(const BgzfParams p)
 {
-    __shared__ uint32_t mask[BGZF_THREADS * BGZF_MASK_WORDS];
-    __shared__ uint32_t lit[256], match[256];
-    __shared__ uint32_t scratch[8];
-    const uint32_t b = blockIdx.x;
-    lit[threadIdx.x] = p.tables->lit[threadIdx.x];
-    match[threadIdx.x] = p.tables->match[threadIdx.x];
-    __syncthreads();
+    __shared__ uint32_t in_lds[BGZF_LDS_IN_WORDS];
+    __shared__ uint32_t tab[512];
+    __shared__ uint32_t scratch[BGZF_WAVES];
+    const uint32_t b = blockIdx.x, tid = threadIdx.x;
+    load_code_table(p, tab);
     const uint32_t N = block_len(p, b);
-    const uint8_t* blk = p.text + (uint64_t)b * BGZF_IN;
-    const uint32_t c0 = threadIdx.x * BGZF_CHUNK;
+    stage_block(p.text + (uint64_t)b * BGZF_IN, N, in_lds);
+    __syncthreads();
+    const uint32_t c0 = tid * BGZF_CHUNK;
     uint32_t bits = 0;
     if (c0 < N) {
         const uint32_t len = min(BGZF_CHUNK, N - c0);
-        uint32_t* mk = mask + threadIdx.x * BGZF_MASK_WORDS;
-        chunk_mask<false>(blk, c0, len, mk, nullptr);
-        CountVisitor v{blk + c0, lit, match, 0};
-        walk_tokens(mk, len, v);
-        bits = v.bits;
+        const ChunkTokens t = chunk_tokens<false>(in_lds, tid, len, nullptr, nullptr);
+        CountSink s{0};
+        walk_tokens(t, reinterpret_cast<const uint8_t*>(in_lds + tid * (BGZF_CHUNK_WORDS + 1u)), tab, s);
+        bits = s.bits;
     }
     uint32_t total;
     block_exclusive_scan(bits, scratch, &total);
-    if (threadIdx.x == 0) {
+    if (tid == 0) {
         const uint32_t body_bits = p.tables->hdr_nbits + total + (p.tables->eob & 31u);
         const uint32_t body = (body_bits + 7u) >> 3;
         const uint32_t stored = N + 5u;
@@ -279,11 +309,11 @@ __device__ __forceinline__ uint32_t crc_mulmod(uint32_t a, uint32_t b)
 
 __global__ __launch_bounds__(BGZF_THREADS) void bgzf_encode(const BgzfParams p)
 {
+    __shared__ uint32_t in_lds[BGZF_LDS_IN_WORDS];
     __shared__ uint32_t outbuf[BGZF_LDS_OUT / 4];
-    __shared__ uint32_t mask[BGZF_THREADS * BGZF_MASK_WORDS];
-    __shared__ uint32_t lit[256], match[256];
+    __shared__ uint32_t tab[512];
     __shared__ uint32_t crc_tab[4][256];
-    __shared__ uint32_t scratch[8];
+    __shared__ uint32_t scratch[BGZF_WAVES];
     const uint32_t b = blockIdx.x, tid = threadIdx.x;
     const uint32_t N = block_len(p, b);
     const uint8_t* blk = p.text + (uint64_t)b * BGZF_IN;
@@ -291,23 +321,23 @@ __global__ __launch_bounds__(BGZF_THREADS) void bgzf_encode(const BgzfParams p)
     const uint32_t size = p.sizes[b] & 0x7FFFFFFFu;
     const bool stored = p.sizes[b] >> 31;
 
-    lit[tid] = p.tables->lit[tid];
-    match[tid] = p.tables->match[tid];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) crc_tab[k][tid] = p.tables->crc_table[k][tid];
+    load_code_table(p, tab);
+    crc_tab[tid >> 8][tid & 255u] = p.tables->crc_table[tid >> 8][tid & 255u];
     for (uint32_t i = tid; i < BGZF_LDS_OUT / 4; i += BGZF_THREADS) outbuf[i] = 0;
+    stage_block(blk, N, in_lds);
     __syncthreads();
 
     const uint32_t c0 = tid * BGZF_CHUNK;
     const uint32_t len = c0 < N ? min(BGZF_CHUNK, N - c0) : 0u;
-    uint32_t* mk = mask + tid * BGZF_MASK_WORDS;
+    const uint8_t* chunk = reinterpret_cast<const uint8_t*>(in_lds + tid * (BGZF_CHUNK_WORDS + 1u));
+    ChunkTokens t{0, 0, 0};
     uint32_t bits = 0, crc = 0;
     if (len) {
-        crc = chunk_mask<true>(blk, c0, len, mk, crc_tab);
+        t = chunk_tokens<true>(in_lds, tid, len, crc_tab, &crc);
         if (!stored) {
-            CountVisitor v{blk + c0, lit, match, 0};
-            walk_tokens(mk, len, v);
-            bits = v.bits;
+            CountSink s{0};
+            walk_tokens(t, chunk, tab, s);
+            bits = s.bits;
         }
     }
     uint32_t total;
@@ -315,37 +345,36 @@ __global__ __launch_bounds__(BGZF_THREADS) void bgzf_encode(const BgzfParams p)
     const uint32_t hdr_bits = p.tables->hdr_nbits;
 
     if (!stored) {
-        for (uint32_t i = tid; i < (hdr_bits + 31u) / 32u; i += BGZF_THREADS) atomicOr(&outbuf[i], p.tables->hdr[i]);
+        if (tid < (hdr_bits + 31u) / 32u) atomicOr(&outbuf[tid], p.tables->hdr[tid]);
         if (len) {
             const uint32_t start = hdr_bits + prefix;
-            EmitVisitor e{blk + c0, lit, match, outbuf, 0, start & 31u, start >> 5};
-            walk_tokens(mk, len, e);
+            EmitSink e{outbuf, 0, start & 31u, start >> 5};
+            walk_tokens(t, chunk, tab, e);
             e.flush();
         }
         if (tid == 0) {
             const uint32_t start = hdr_bits + total;
-            EmitVisitor e{blk, lit, match, outbuf, 0, start & 31u, start >> 5};
-            e.put(p.tables->eob);
+            EmitSink e{outbuf, 0, start & 31u, start >> 5};
+            e.token(p.tables->eob, 256u);
             e.flush();
         }
     }
     // CRC-32 of the block: combine the chunk CRCs, crc(A||B) = crc(A) * x^(8|B|) + crc(B)
-    {
-        uint32_t part = 0;
-        if (len) {
-            const uint32_t after = N - (c0 + len);       // bytes behind this chunk
-            const uint32_t q = after / BGZF_CHUNK, r = after - q * BGZF_CHUNK;
-            uint32_t sh = p.tables->crc_shift_chunk[q];
-            if (r) sh = crc_mulmod(sh, p.tables->crc_shift_byte[r]);
-            part = after ? crc_mulmod(sh, crc) : crc;
-        }
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) part ^= __shfl_xor(part, d, 64);
-        __syncthreads();
-        if ((tid & 63u) == 0) scratch[tid >> 6] = part;
+    uint32_t part = 0;
+    if (len) {
+        const uint32_t after = N - (c0 + len); // bytes behind this chunk
+        const uint32_t q = after / BGZF_CHUNK, r = after - q * BGZF_CHUNK;
+        uint32_t sh = p.tables->crc_shift_chunk[q];
+        if (r) sh = crc_mulmod(sh, p.tables->crc_shift_byte[r]);
+        part = after ? crc_mulmod(sh, crc) : crc;
     }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) part ^= __shfl_xor(part, d, 64);
+    __syncthreads(); // scratch is free again, and outbuf is complete
+    if ((tid & 63u) == 0) scratch[tid >> 6] = part;
     __syncthreads();
-    const uint32_t block_crc = scratch[0] ^ scratch[1] ^ scratch[2] ^ scratch[3];
+    uint32_t block_crc = 0;
+    for (uint32_t w = 0; w < BGZF_WAVES; ++w) block_crc ^= scratch[w];
 
     // gzip member header (RFC 1952) with the BGZF extra field: BSIZE = member size - 1
     if (tid < 18) {
@@ -362,7 +391,8 @@ __global__ __launch_bounds__(BGZF_THREADS) void bgzf_encode(const BgzfParams p)
             body[1] = (uint8_t)(N & 0xFFu); body[2] = (uint8_t)(N >> 8);
             body[3] = (uint8_t)(~N & 0xFFu); body[4] = (uint8_t)((~N >> 8) & 0xFFu);
         }
-        for (uint32_t i = tid; i < N; i += BGZF_THREADS) body[5 + i] = blk[i];
+        const uint8_t* src = reinterpret_cast<const uint8_t*>(in_lds);
+        for (uint32_t i = tid; i < N; i += BGZF_THREADS) body[5 + i] = src[4u * lds_word(i >> 2) + (i & 3u)];
     } else {
         body_bytes = size - BGZF_MEMBER_OVERHEAD;
         const uint8_t* src = reinterpret_cast<const uint8_t*>(outbuf);

@@ -48,8 +48,8 @@ def _tables(capi, lit_hist, match_hist, n_eob):
     assert rc == 0
     t = {"lit": blob[0:256], "match": blob[256:512], "eob": int(blob[512]), "hdr_nbits": int(blob[513]),
          "hdr": blob[514:562], "crc_table": blob[562:562 + 1024].reshape(4, 256),
-         "shift_chunk": blob[1586:1842], "shift_byte": blob[1842:2098]}
-    assert len(blob) == 2098
+         "shift_chunk": blob[1586:2610], "shift_byte": blob[2610:2866]}
+    assert len(blob) == 2866
     return t
 
 
@@ -119,9 +119,9 @@ def test_encoder_crc_constants(capi):
             b = (b >> 1) ^ 0xEDB88320 if b & 1 else b >> 1
         return r
 
-    a, b = os.urandom(252 * 3), os.urandom(252 * 2 + 17)
+    a, b = os.urandom(64 * 3), os.urandom(64 * 2 + 17)
     assert crc_bytes(a) == zlib.crc32(a)
-    # crc(A || B) = crc(A) * x^(8|B|) + crc(B), with |B| = 252*2 + 17 split into the chunk and byte tables
+    # crc(A || B) = crc(A) * x^(8|B|) + crc(B), with |B| = 64*2 + 17 split into the chunk and byte tables
     sh = mulmod(int(t["shift_chunk"][2]), int(t["shift_byte"][17]))
     assert mulmod(sh, zlib.crc32(a)) ^ zlib.crc32(b) == zlib.crc32(a + b)
     # slicing tables: one dword step equals four byte steps

@@ -100,6 +100,14 @@ def test_cli_end_to_end_matches_oracle(oracle, tmp_path):
     sizes = bgzf.block_sizes(str(out / "population.vcf.gz"))
     assert sizes[-1] == 28 and max(sizes) <= 65536
 
+    # --host-bgzf (zlib at -z, like the reference) produces the same decompressed file
+    out3 = tmp_path / "run3"
+    r = _run_cli(["-s", "70", "-c", "90", "-x", "1500", "-f", "0.01", "-z", "2", "--seed", "4242", "--host-bgzf",
+                  "--outdir", str(out3)])
+    assert r.returncode == 0, r.stderr
+    vcf3 = gzip.open(out3 / "population.vcf.gz", "rb").read()
+    assert vcf3.split(b"#CHROM", 1)[1] == vcf.split(b"#CHROM", 1)[1]
+
     # same seed, SNP list and deleterious set on two shards (two contexts) -> identical decompressed VCF body
     out2 = tmp_path / "run2"
     r = _run_cli(["-s", "70", "-c", "90", "--seed", "4242", "--snps_file", str(out / "snps.json.gz"),
