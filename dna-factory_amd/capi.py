@@ -32,7 +32,7 @@ SYMBOLS = [
     "dnaf_reserve_output",
     "dnaf_sync", "dnaf_last_generate_ms", "dnaf_timing_begin", "dnaf_timing_end", "dnaf_read_text", "dnaf_read_packed", "dnaf_device_buffers",
     "dnaf_format_prefixes", "dnaf_bgzf_compress", "dnaf_read_bgzf", "dnaf_last_bgzf_ms",
-    "dnaf_bgzf_tables_from_histogram",
+    "dnaf_bgzf_tables_from_histogram", "dnaf_set_mt_state", "dnaf_mt_jump_host", "dnaf_mt_characteristic_polynomial",
 ]
 
 
@@ -88,6 +88,9 @@ def _load():
         "dnaf_read_bgzf": (ci, [vp, vp, u64, vp]),
         "dnaf_last_bgzf_ms": (ci, [vp, vp]),
         "dnaf_bgzf_tables_from_histogram": (ci, [vp, vp, u64, vp, u64, vp]),
+        "dnaf_set_mt_state": (ci, [vp, vp, u32, u64]),
+        "dnaf_mt_jump_host": (ci, [vp, u64, vp]),
+        "dnaf_mt_characteristic_polynomial": (ci, [vp, vp]),
     }
     for name in SYMBOLS:
         fn = getattr(lib, name)  # AttributeError here = the library does not export what the header declares
@@ -181,6 +184,13 @@ class Context:
 
     def set_rng(self, mode, seed, rng_row0=0):
         self._check(lib.dnaf_set_rng(self._h, mode, int(seed) & 0xFFFFFFFFFFFFFFFF, int(rng_row0)))
+
+    def set_mt_state(self, key, pos, rng_row0=0):
+        """MT19937 mode from numpy.random.get_state()[1:3] (the stream position the reference's worker starts at)."""
+        key = np.ascontiguousarray(key, dtype=np.uint32)
+        if key.shape != (624,):
+            raise ValueError("key must hold 624 words")
+        self._check(lib.dnaf_set_mt_state(self._h, ptr(key), int(pos), int(rng_row0)))
 
     def set_snps(self, snp_id, chrom_class, n_alleles, cum_freq, prefix_bytes, prefix_off):
         n = len(snp_id)

@@ -7,12 +7,15 @@
 #include "../../include/dnaf.h"
 #include "rowgen_kernels.hip.h"
 #include "bgzf_kernels.hip.h"
+#include "mt_jump.h"
+#include "mt_kernels.hip.h"
 
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <new>
 #include <string>
 #include <unordered_map>
@@ -61,6 +64,19 @@ struct dnaf_ctx {
     uint64_t last_begin = 0, last_rows = 0;
     uint32_t last_what = 0;
     bool have_output = false;
+
+    // numpy-compatible MT19937 mode
+    uint32_t mt_key[624] = {0};          // the worker's entry state: numpy.random.get_state()[1]
+    uint32_t mt_pos = 624;               // ... and [2]
+    std::vector<uint64_t> h_thr53;       // [n_rows][3] thresholds on the 53-bit roll numerator
+    bool thr53_ok = true;                // every row's last cumulative frequency covers every 53-bit roll
+    uint64_t* d_thr53 = nullptr;
+    uint32_t* d_mt_base = nullptr;       // entry window on the device
+    uint32_t* d_mt_states = nullptr;     // [mt_cap][624] block-aligned windows of waves [mt_lo, mt_lo + mt_n)
+    uint32_t* d_mt_tmp = nullptr;
+    uint64_t mt_cap = 0, mt_lo = 0, mt_n = 0;
+    bool mt_valid = false;
+    std::map<uint64_t, uint64_t*> mt_polys; // jump distance in words -> device polynomial (312 x u64)
 
     // BGZF encoder
     dnaf::BgzfTables* d_tables = nullptr;
@@ -162,6 +178,11 @@ int dnaf_destroy(dnaf_ctx* c)
     dev_free(c->d_prefix);
     dev_free(c->d_text);
     dev_free(c->d_packed);
+    dev_free(c->d_thr53);
+    dev_free(c->d_mt_base);
+    dev_free(c->d_mt_states);
+    dev_free(c->d_mt_tmp);
+    for (auto& kv : c->mt_polys) (void)hipFree(kv.second);
     dev_free(c->d_tables);
     dev_free(c->d_hist);
     dev_free(c->d_sizes);
@@ -257,13 +278,44 @@ int dnaf_set_forced(dnaf_ctx* c, const int64_t* snp_ids, uint64_t n_slots, const
 int dnaf_set_rng(dnaf_ctx* c, uint32_t mode, uint64_t seed, uint64_t rng_row0)
 {
     if (!c) return DNAF_ERR_BAD_ARG;
-    if (mode == DNAF_RNG_MT19937)
-        return fail(c, DNAF_ERR_UNSUPPORTED, "dnaf_set_rng: DNAF_RNG_MT19937 is not implemented in this build");
-    if (mode != DNAF_RNG_PHILOX) return fail(c, DNAF_ERR_BAD_ARG, "dnaf_set_rng: unknown mode %u", mode);
+    if (mode != DNAF_RNG_PHILOX && mode != DNAF_RNG_MT19937) return fail(c, DNAF_ERR_BAD_ARG, "dnaf_set_rng: unknown mode %u", mode);
+    if (mode == DNAF_RNG_MT19937) {
+        // numpy.random.seed(int): init_genrand, valid for 0 .. 2^32-1 (pop_factory.py:235)
+        if (seed > 0xFFFFFFFFull) return fail(c, DNAF_ERR_BAD_ARG, "dnaf_set_rng: an MT19937 seed must be below 2^32 (numpy.random.seed)");
+        if (c->rng_mode != mode || c->seed != seed || c->mt_pos != 624) {
+            dnaf::mt_init_genrand((uint32_t)seed, c->mt_key);
+            c->mt_pos = 624;
+            c->mt_valid = false;
+            dev_free(c->d_mt_base);
+        }
+    }
     c->rng_mode = mode;
     c->seed = seed;
     c->rng_row0 = rng_row0;
     return DNAF_OK;
+}
+
+int dnaf_set_mt_state(dnaf_ctx* c, const uint32_t* key, uint32_t pos, uint64_t rng_row0)
+{
+    if (!c) return DNAF_ERR_BAD_ARG;
+    if (!key || pos > 624) return fail(c, DNAF_ERR_BAD_ARG, "dnaf_set_mt_state: key is NULL or pos > 624");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    memcpy(c->mt_key, key, sizeof c->mt_key);
+    c->mt_pos = pos;
+    c->mt_valid = false;
+    dev_free(c->d_mt_base);
+    c->rng_mode = DNAF_RNG_MT19937;
+    c->seed = 0xFFFFFFFFFFFFFFFFull; // an explicit state, not a seed
+    c->rng_row0 = rng_row0;
+    return DNAF_OK;
+}
+
+// floor(cum * 2^53) clamped to 2^53: `cum >= r * 2^-53` <=> r <= T for the numerators r < 2^53 of numpy's doubles
+static uint64_t threshold_u53(double cum)
+{
+    const double s = std::floor(cum * 9007199254740992.0);
+    return s >= 9007199254740992.0 ? (1ull << 53) : (uint64_t)s;
 }
 
 // floor(cum * 2^32) clamped to u32: `cum >= u * 2^-32` <=> u <= T (both sides exact in float64)
@@ -288,10 +340,13 @@ int dnaf_set_snps(dnaf_ctx* c, const dnaf_snp_table* t)
     c->have_snps = c->have_output = false;
     dev_free(c->d_recs);
     dev_free(c->d_prefix);
+    dev_free(c->d_thr53);
+    c->thr53_ok = true;
     std::vector<RowRec> recs;
     try {
         recs.resize((size_t)n);
         c->h_text_off.assign((size_t)n + 1, 0);
+        c->h_thr53.assign((size_t)n * 3, 1ull << 53);
     } catch (const std::bad_alloc&) {
         return fail(c, DNAF_ERR_OOM, "dnaf_set_snps: host allocation for %llu rows", (unsigned long long)n);
     }
@@ -313,6 +368,8 @@ int dnaf_set_snps(dnaf_ctx* c, const dnaf_snp_table* t)
             return fail(c, DNAF_ERR_THRESHOLD, "dnaf_set_snps: row %llu last cumulative frequency %.17g < 1: a roll above it has no allele "
                         "(the reference raises TypeError, pop_factory.py:489)", (unsigned long long)j, t->cum_freq[j * DNAF_MAX_ALLELES + na - 1]);
         r.thr[0] = thr[0]; r.thr[1] = thr[1]; r.thr[2] = thr[2];
+        for (uint32_t k = 0; k < na && k < 3; ++k) c->h_thr53[(size_t)j * 3 + k] = threshold_u53(t->cum_freq[j * DNAF_MAX_ALLELES + k]);
+        if (S && threshold_u53(t->cum_freq[j * DNAF_MAX_ALLELES + na - 1]) < (1ull << 53) - 1) c->thr53_ok = false;
         if (t->prefix_off[j + 1] < t->prefix_off[j]) return fail(c, DNAF_ERR_BAD_ARG, "dnaf_set_snps: prefix_off not monotone at row %llu", (unsigned long long)j);
         const uint64_t plen = t->prefix_off[j + 1] - t->prefix_off[j], poff = t->prefix_off[j] - pbase;
         if (plen > 0xFFFFu || poff > 0xFFFFFFFFull)
@@ -393,6 +450,152 @@ int dnaf_reserve_output(dnaf_ctx* c, uint64_t text_bytes, uint64_t packed_words)
     return grow_outputs(c, text_bytes, packed_words * 4u);
 }
 
+// ---- numpy-compatible MT19937 mode (mt_kernels.hip.h) ----
+static dnaf::MtJumper& mt_jumper()
+{
+    static dnaf::MtJumper j;
+    j.init();
+    return j;
+}
+
+static uint64_t gcd_u64(uint64_t a, uint64_t b) { while (b) { const uint64_t t = a % b; a = b; b = t; } return a; }
+
+// device polynomial x^(J-1) mod phi for a jump of J >= 1 words (cached per distance)
+static int mt_poly_for(dnaf_ctx* c, uint64_t J, const uint64_t** out)
+{
+    auto it = c->mt_polys.find(J);
+    if (it == c->mt_polys.end()) {
+        dnaf::MtPoly g;
+        mt_jumper().xpow_mod(J - 1, &g);
+        uint64_t* d = nullptr;
+        HIP_TRY(c, hipMalloc((void**)&d, sizeof g.w));
+        hipError_t e = hipMemcpy(d, g.w, sizeof g.w, hipMemcpyHostToDevice);
+        if (e != hipSuccess) { (void)hipFree(d); return fail(c, DNAF_ERR_HIP, "mt_poly_for: %s", hipGetErrorString(e)); }
+        it = c->mt_polys.emplace(J, d).first;
+    }
+    *out = it->second;
+    return DNAF_OK;
+}
+
+// Make d_mt_states hold the block-aligned windows of waves [lo, lo + n): wave k starts at output word
+// k * words_per_wave after the entry state, i.e. in block k * D + (pos == 624) of the word sequence.
+static int mt_prepare_states(dnaf_ctx* c, uint64_t lo, uint64_t n, uint64_t D)
+{
+    if (c->mt_valid && c->mt_lo == lo && c->mt_n >= n) return DNAF_OK;
+    if (n > c->mt_cap) {
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        uint32_t *a = nullptr, *b = nullptr;
+        HIP_TRY(c, hipMalloc((void**)&a, n * 624 * sizeof(uint32_t)));
+        HIP_TRY(c, hipMalloc((void**)&b, n * 624 * sizeof(uint32_t)));
+        if (c->mt_valid && c->mt_n) HIP_TRY(c, hipMemcpy(a, c->d_mt_states, c->mt_n * 624 * sizeof(uint32_t), hipMemcpyDeviceToDevice));
+        dev_free(c->d_mt_states);
+        dev_free(c->d_mt_tmp);
+        c->d_mt_states = a;
+        c->d_mt_tmp = b;
+        c->mt_cap = n;
+    }
+    if (!c->d_mt_base) {
+        HIP_TRY(c, hipMalloc((void**)&c->d_mt_base, sizeof c->mt_key));
+        HIP_TRY(c, hipMemcpy(c->d_mt_base, c->mt_key, sizeof c->mt_key, hipMemcpyHostToDevice));
+    }
+    const uint64_t* poly = nullptr;
+    if (c->mt_valid && lo == c->mt_lo + c->mt_n && n <= c->mt_n) {
+        // the next tile of a sequential sweep: every cached state advances by the same distance
+        if (int rc = mt_poly_for(c, c->mt_n * D * 624, &poly)) return rc;
+        hipLaunchKernelGGL(dnaf::mt_jump_kernel, dim3((uint32_t)c->mt_n), dim3(640), 0, c->stream, (const uint32_t*)c->d_mt_states,
+                           (const uint32_t*)nullptr, c->d_mt_tmp, poly);
+        HIP_TRY(c, hipGetLastError());
+        std::swap(c->d_mt_states, c->d_mt_tmp);
+        c->mt_lo = lo;
+        return DNAF_OK;
+    }
+    // rebuild: first state by one jump from the entry window, the rest by doubling
+    c->mt_valid = false;
+    const uint64_t blk0 = lo * D + (c->mt_pos == 624 ? 1 : 0);
+    if (blk0 == 0) {
+        HIP_TRY(c, hipMemcpyAsync(c->d_mt_states, c->d_mt_base, sizeof c->mt_key, hipMemcpyDeviceToDevice, c->stream));
+    } else {
+        if (blk0 > 0xFFFFFFFFFFFFFFFFull / 624) return fail(c, DNAF_ERR_UNSUPPORTED, "dnaf_generate: MT19937 stream position overflows 64 bits");
+        if (int rc = mt_poly_for(c, blk0 * 624, &poly)) return rc;
+        hipLaunchKernelGGL(dnaf::mt_jump_kernel, dim3(1), dim3(640), 0, c->stream, (const uint32_t*)c->d_mt_base, (const uint32_t*)nullptr,
+                           c->d_mt_states, poly);
+        HIP_TRY(c, hipGetLastError());
+    }
+    for (uint64_t have = 1; have < n; have *= 2) {
+        const uint64_t cnt = have < n - have ? have : n - have;
+        if (int rc = mt_poly_for(c, have * D * 624, &poly)) return rc;
+        hipLaunchKernelGGL(dnaf::mt_jump_kernel, dim3((uint32_t)cnt), dim3(640), 0, c->stream, (const uint32_t*)c->d_mt_states,
+                           (const uint32_t*)nullptr, c->d_mt_states + have * 624, poly);
+        HIP_TRY(c, hipGetLastError());
+    }
+    c->mt_lo = lo;
+    c->mt_n = n;
+    c->mt_valid = true;
+    return DNAF_OK;
+}
+
+static int generate_mt(dnaf_ctx* c, uint64_t row_begin, uint64_t n_rows, uint32_t what)
+{
+    if (!c->thr53_ok)
+        return fail(c, DNAF_ERR_THRESHOLD, "dnaf_generate: a row's last cumulative frequency is below 1: a 53-bit roll above it has no allele "
+                    "(the reference raises TypeError, pop_factory.py:489)");
+    const uint64_t S = c->S;
+    const uint64_t R = 156 / gcd_u64(S, 156);   // rows per wave: 4*S*R is a multiple of 624
+    const uint64_t D = 4 * S * R / 624;         // blocks per wave
+    const uint64_t rng_row = c->rng_row0 + row_begin;
+    if (rng_row % R)
+        return fail(c, DNAF_ERR_UNSUPPORTED, "dnaf_generate: in MT19937 mode a range must start on a multiple of %llu rows "
+                    "(RNG row %llu does not), so that every wave starts on a block of the stream", (unsigned long long)R, (unsigned long long)rng_row);
+    const uint64_t n_waves = (n_rows + R - 1) / R;
+    if (n_waves > 0x7FFFFFFFull) return fail(c, DNAF_ERR_UNSUPPORTED, "dnaf_generate: too many waves; generate fewer rows per call");
+    if (!c->d_thr53) {
+        HIP_TRY(c, hipMalloc((void**)&c->d_thr53, c->h_thr53.size() * sizeof(uint64_t) + 8));
+        HIP_TRY(c, hipMemcpy(c->d_thr53, c->h_thr53.data(), c->h_thr53.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
+    }
+    const bool rec = c->n_timed < MAX_TIMED;
+    if (rec && c->evs.size() < 2 * (c->n_timed + 1)) {
+        hipEvent_t a = nullptr, b = nullptr;
+        HIP_TRY(c, hipEventCreate(&a));
+        c->evs.push_back(a);
+        HIP_TRY(c, hipEventCreate(&b));
+        c->evs.push_back(b);
+    }
+    if (rec) HIP_TRY(c, hipEventRecord(c->evs[2 * c->n_timed], c->stream));
+    if (int rc = mt_prepare_states(c, rng_row / R, n_waves, D)) return rc;
+    dnaf::MtGenParams mp;
+    GenParams& p = mp.g;
+    p.recs = c->d_recs;
+    p.prefix = c->d_prefix;
+    p.male_nib = c->d_male_nib;
+    p.xoff = c->d_xoff;
+    p.forced = c->d_forced;
+    p.text = c->d_text;
+    p.packed = c->d_packed;
+    p.text_base = c->h_text_off[(size_t)row_begin];
+    p.row_begin = row_begin;
+    p.n_rows = n_rows;
+    p.rng_row0 = c->rng_row0;
+    p.key0 = p.key1 = 0;
+    p.S = c->S; p.G = c->G; p.W = c->W;
+    p.nseg = 1; p.seg_groups = 64;
+    mp.thr53 = c->d_thr53;
+    mp.states = c->d_mt_states;
+    mp.start_off = c->mt_pos == 624 ? 0 : c->mt_pos;
+    mp.rows_per_wave = (uint32_t)R;
+    mp.wave0_row = 0;
+    const dim3 grid((uint32_t)n_waves), block(64);
+    if (what == (DNAF_OUT_TEXT | DNAF_OUT_PACKED)) hipLaunchKernelGGL((dnaf::mt_rowgen_kernel<true, true>), grid, block, 0, c->stream, mp);
+    else if (what == DNAF_OUT_TEXT) hipLaunchKernelGGL((dnaf::mt_rowgen_kernel<true, false>), grid, block, 0, c->stream, mp);
+    else hipLaunchKernelGGL((dnaf::mt_rowgen_kernel<false, true>), grid, block, 0, c->stream, mp);
+    HIP_TRY(c, hipGetLastError());
+    if (rec) {
+        HIP_TRY(c, hipEventRecord(c->evs[2 * c->n_timed + 1], c->stream));
+        ++c->n_timed;
+    }
+    ++c->n_launches;
+    return DNAF_OK;
+}
+
 int dnaf_generate(dnaf_ctx* c, uint64_t row_begin, uint64_t n_rows, uint32_t what)
 {
     if (!c) return DNAF_ERR_BAD_ARG;
@@ -410,6 +613,7 @@ int dnaf_generate(dnaf_ctx* c, uint64_t row_begin, uint64_t n_rows, uint32_t wha
     c->have_output = true;
     c->have_bgzf = false;
     if (n_rows == 0) return DNAF_OK;
+    if (c->rng_mode == DNAF_RNG_MT19937 && c->S) return generate_mt(c, row_begin, n_rows, what); // S == 0 draws nothing
 
     GenParams p;
     p.recs = c->d_recs;
@@ -713,6 +917,35 @@ int dnaf_format_prefixes(uint64_t n, const char* chrom, uint32_t chrom_w, const 
         o += need;
     }
     off[n] = o;
+    return DNAF_OK;
+}
+
+} // extern "C"
+
+// ---- numpy-compatible MT19937 mode: host-side jump helpers (also used by CPU tests) ----
+extern "C" {
+
+// window[624] = the 624 untempered words that start J >= 1 words after base[624] in the MT19937 word
+// sequence (host evaluation, O(19937 * 624); tests and one-off jumps only).
+int dnaf_mt_jump_host(const uint32_t* base, uint64_t J, uint32_t* window)
+{
+    if (!base || !window || J == 0) return DNAF_ERR_BAD_ARG;
+    dnaf::MtPoly g;
+    mt_jumper().xpow_mod(J - 1, &g);
+    dnaf::mt_jump_window_host(base, g, window);
+    return DNAF_OK;
+}
+
+// degree and coefficient words (312 x u64) of the characteristic polynomial (tests)
+int dnaf_mt_characteristic_polynomial(uint64_t* words312, int* degree)
+{
+    if (!words312 || !degree) return DNAF_ERR_BAD_ARG;
+    const dnaf::MtPoly& phi = mt_jumper().phi;
+    memcpy(words312, phi.w, sizeof phi.w);
+    int d = -1;
+    for (int i = dnaf::MT_POLY_WORDS * 64 - 1; i >= 0 && d < 0; --i)
+        if ((phi.w[i / 64] >> (i % 64)) & 1ull) d = i;
+    *degree = d;
     return DNAF_OK;
 }
 

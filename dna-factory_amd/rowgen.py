@@ -18,15 +18,37 @@ RNG_MODES = {"philox": capi.RNG_PHILOX, "mt19937": capi.RNG_MT19937}
 
 
 class RowGenerator:
-    def __init__(self, device=0, seed=0, rng="philox"):
+    def __init__(self, device=0, seed=0, rng="philox", mt_state=None):
+        """rng="philox": Philox4x32-10 keyed by `seed`.  rng="mt19937": numpy's legacy stream,
+        either from `seed` (= numpy.random.seed(seed), what the unmodified reference worker draws when it is
+        called right after seeding) or from an explicit `mt_state` = numpy.random.get_state()[1:3]."""
         if rng not in RNG_MODES:
             raise ValueError("rng must be one of %s" % sorted(RNG_MODES))
+        if mt_state is not None and rng != "mt19937":
+            raise ValueError("mt_state needs rng='mt19937'")
         self.ctx = capi.Context(device)
         self.seed = int(seed)
         self.rng = rng
-        self.ctx.set_rng(RNG_MODES[rng], self.seed, 0)
+        self.mt_state = None if mt_state is None else (np.array(mt_state[0], dtype=np.uint32), int(mt_state[1]))
+        self._set_rng(0)
         self.n_samples = None
         self.n_rows = None
+
+    def _set_rng(self, rng_row0):
+        if self.mt_state is not None:
+            self.ctx.set_mt_state(self.mt_state[0], self.mt_state[1], rng_row0)
+        else:
+            self.ctx.set_rng(RNG_MODES[self.rng], self.seed, rng_row0)
+
+    @property
+    def row_quantum(self):
+        """Row ranges must start on a multiple of this many rows (1 for Philox; in MT19937 mode waves start on block
+        boundaries of the sequential stream, every 156 / gcd(S, 156) rows)."""
+        if self.rng != "mt19937" or not self.n_samples:
+            return 1
+        from math import gcd
+
+        return 156 // gcd(self.n_samples, 156)
 
     def close(self):
         self.ctx.close()
@@ -54,7 +76,7 @@ class RowGenerator:
             raise capi.DnafError(capi.ERR_STATE, "set_samples must be called before set_snps")
         tb = snps if isinstance(snps, SnpTable) else SnpTable.from_snps(snps)
         blob, off = tb.prefixes()
-        self.ctx.set_rng(RNG_MODES[self.rng], self.seed, rng_row0)
+        self._set_rng(rng_row0)
         self.ctx.set_snps(tb.snp_id, tb.chrom_class, tb.n_alleles, tb.cum, blob, off)
         self.n_rows = len(tb)
         return tb
@@ -103,6 +125,8 @@ class RowGenerator:
             # keep a tile's text near 256 MiB
             per_row = 64 + 4 * max(self.n_samples, 1)
             tile_rows = max(1, min(n, (256 << 20) // per_row)) if n else 1
+        q = self.row_quantum
+        tile_rows = max(q, tile_rows // q * q)
         as_text = isinstance(file, io.TextIOBase)
         for b in range(0, n, tile_rows):
             m = min(tile_rows, n - b)

@@ -52,7 +52,9 @@ extern "C" {
 /* RNG that stands in for numpy.random.rand(2*S) of pop_factory.py:477 */
 #define DNAF_RNG_PHILOX 0u  /* Philox4x32-10, one 32-bit word per draw; rocRAND sequence
                                (seed, subsequence = RNG row, offset = 2*sample + allele)  */
-#define DNAF_RNG_MT19937 1u /* numpy legacy stream (53-bit doubles from MT19937)          */
+#define DNAF_RNG_MT19937 1u /* numpy legacy stream (53-bit doubles from MT19937): the unmodified
+                               reference after numpy.random.seed(seed); ranges must start on a
+                               multiple of 156 / gcd(S, 156) rows                          */
 
 /* what dnaf_generate materialises */
 #define DNAF_OUT_TEXT 1u   /* VCF body lines, pop_factory.py:503-508                       */
@@ -98,6 +100,12 @@ int dnaf_set_forced(dnaf_ctx* ctx, const int64_t* snp_ids, uint64_t n_slots,
  * row index when the table is one shard of a larger job), so any shard of a
  * job reproduces the bytes of the whole job.  May be called at any time. */
 int dnaf_set_rng(dnaf_ctx* ctx, uint32_t mode, uint64_t seed, uint64_t rng_row0);
+
+/* MT19937 mode with an explicit generator state instead of a seed: key[624] and pos are
+ * numpy.random.get_state()[1] and [2] at the moment the reference's worker would start drawing
+ * (pop_factory.py:432-434, :477), so that a run whose host side replays the reference's earlier
+ * numpy calls continues the very same stream. */
+int dnaf_set_mt_state(dnaf_ctx* ctx, const uint32_t* key, uint32_t pos, uint64_t rng_row0);
 
 /* Upload the SNP table (the work_q argument, pop_factory.py:474) and lay out
  * the output: per-row integer thresholds, forced slot, text offsets. */
@@ -151,6 +159,10 @@ int dnaf_read_bgzf(dnaf_ctx* ctx, void* dst, uint64_t dst_cap, uint64_t* n_bytes
 int dnaf_last_bgzf_ms(dnaf_ctx* ctx, float* ms);
 /* Host-only helper: the encoder's code tables for a token histogram (256 literal counts, 256 counts
  * of match lengths 3..258, end-of-block count); out receives an opaque table blob. */
+/* Host-only helpers of the MT19937 mode (tests): the window of 624 untempered words J >= 1 words after
+ * base[624]; the characteristic polynomial of the generator (312 coefficient words, degree). */
+int dnaf_mt_jump_host(const uint32_t* base, uint64_t J, uint32_t* window);
+int dnaf_mt_characteristic_polynomial(uint64_t* words312, int* degree);
 int dnaf_bgzf_tables_from_histogram(const uint64_t* lit_hist, const uint64_t* match_hist, uint64_t n_eob, void* out,
                                     uint64_t out_cap, uint64_t* size);
 

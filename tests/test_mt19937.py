@@ -1,0 +1,143 @@
+"""numpy-compatible MT19937 mode: jump-ahead machinery (CPU) and the GPU path against the UNMODIFIED reference
+(fixtures `lines_mt`: pop_factory.py:471-513 after numpy.random.seed(k), no patching) and the oracle's MT mode."""
+import ctypes
+
+import numpy as np
+import pytest
+
+from helpers import golden_inputs, golden_names, load_golden, random_case
+
+
+@pytest.fixture(scope="module")
+def capi():
+    import __graft_entry__ as ge
+
+    ge.build()
+    from dna_factory_amd import capi
+
+    return capi
+
+
+def _regen(k):
+    k = k.copy()
+    for i in range(624):
+        y = (int(k[i]) & 0x80000000) | (int(k[(i + 1) % 624]) & 0x7FFFFFFF)
+        k[i] = int(k[(i + 397) % 624]) ^ (y >> 1) ^ (0x9908B0DF if y & 1 else 0)
+    return k
+
+
+def test_characteristic_polynomial(capi):
+    w = np.zeros(312, np.uint64)
+    d = ctypes.c_int(0)
+    assert capi.lib.dnaf_mt_characteristic_polynomial(capi.ptr(w), ctypes.byref(d)) == 0
+    assert d.value == 19937
+    assert sum(bin(int(x)).count("1") for x in w) == 135  # the known weight of MT19937's characteristic polynomial
+
+
+def test_host_jump_matches_stepping_and_numpy(capi):
+    np.random.seed(4242)
+    key = np.random.get_state()[1].astype(np.uint32)
+    blocks = [key]
+    for _ in range(4):
+        blocks.append(_regen(blocks[-1]))
+    seq = np.concatenate(blocks)
+    out = np.zeros(624, np.uint32)
+    for J in (1, 2, 226, 227, 623, 624, 625, 1871):
+        assert capi.lib.dnaf_mt_jump_host(capi.ptr(key), J, capi.ptr(out)) == 0
+        assert np.array_equal(out, seq[J: J + 624])
+    # a long jump against numpy itself: consuming 624 * k words leaves numpy's key = the window k blocks later
+    J = 624 * 7001
+    np.random.rand(J // 2)
+    st = np.random.get_state()
+    assert st[2] == 624
+    assert capi.lib.dnaf_mt_jump_host(capi.ptr(key), J, capi.ptr(out)) == 0
+    assert np.array_equal(out, st[1].astype(np.uint32))
+
+
+@pytest.fixture(scope="module")
+def RowGenerator(capi):
+    from dna_factory_amd.rowgen import RowGenerator
+
+    return RowGenerator
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", [n for n in golden_names() if not n.endswith("_philox")])
+def test_gpu_mt19937_reproduces_the_unmodified_reference(RowGenerator, name):
+    doc = load_golden(name)
+    if doc.get("lines_mt") is None:
+        pytest.skip("fixture has no MT lines")
+    snps, samples = golden_inputs(doc)
+    st = (doc["mt_state_key"], doc["mt_state_pos"]) if "mt_state_key" in doc else None
+    with RowGenerator(device=0, seed=doc["seed"], rng="mt19937", mt_state=st) as g:
+        g.set_samples(samples)
+        g.set_snps(snps)
+        assert g.lines() == doc["lines_mt"]
+
+
+def _oracle_mt(orc, snps, samples, seed, rng_row0=0, mt_state=None):
+    rec = orc.snp_records(snps)
+    sex, ctrl, off, ids = orc.sample_arrays(samples)
+    return orc.generate(rec, sex, ctrl, off, ids, rng_mode=orc.RNG_MT19937, seed=seed, rng_row0=rng_row0, mt_state=mt_state)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_rows,S", [(5, 1), (40, 3), (200, 39), (45, 156), (30, 257), (90, 1000), (8, 20000)])
+def test_gpu_mt19937_matches_oracle(RowGenerator, oracle, n_rows, S):
+    rs = np.random.RandomState(n_rows * 7 + S)
+    snps, samples = random_case(rs, n_rows, S)
+    seed = int(rs.randint(0, 2**31))
+    want_text, want_off, want_packed = _oracle_mt(oracle, snps, samples, seed)
+    with RowGenerator(device=0, seed=seed, rng="mt19937") as g:
+        g.set_samples(samples)
+        g.set_snps(snps)
+        text, off, packed = g.generate()
+        t_only, _, _ = g.generate(text=True, packed=False)
+    assert np.array_equal(off, want_off)
+    assert text.tobytes() == want_text
+    assert np.array_equal(packed, want_packed)
+    assert t_only.tobytes() == want_text
+
+
+@pytest.mark.gpu
+def test_gpu_mt19937_tiles_and_explicit_state(RowGenerator, oracle):
+    """Sequential tiles (states advance by one jump per tile), random access (rebuild), and a mid-block entry state."""
+    rs = np.random.RandomState(31)
+    S = 52  # 156 / gcd(52, 156) = 3 rows per wave
+    snps, samples = random_case(rs, 300, S)
+    np.random.seed(99)
+    np.random.rand(1234)  # the parent has drawn before the worker starts: entry position is mid-block
+    st = np.random.get_state()
+    state = (st[1].astype(np.uint32), int(st[2]))
+    assert 0 < state[1] < 624
+    want_text, want_off, want_packed = _oracle_mt(oracle, snps, samples, 0, mt_state=state)
+    with RowGenerator(device=0, rng="mt19937", mt_state=state) as g:
+        g.set_samples(samples)
+        g.set_snps(snps)
+        assert g.row_quantum == 3
+        pieces = []
+        for b in range(0, 300, 60):  # sequential tiles of 20 waves each
+            t, _, p = g.generate(b, 60)
+            pieces.append(t.tobytes())
+            assert np.array_equal(p, want_packed[b: b + 60])
+        assert b"".join(pieces) == want_text
+        for b, n in ((240, 60), (0, 3), (150, 33), (297, 3)):  # random access
+            t, _, _ = g.generate(b, n)
+            assert t.tobytes() == want_text[int(want_off[b]): int(want_off[b + n])]
+        from dna_factory_amd import capi
+
+        with pytest.raises(capi.DnafError) as e:
+            g.generate(1, 3)  # not on a wave boundary
+        assert e.value.code == capi.ERR_UNSUPPORTED
+
+
+@pytest.mark.gpu
+def test_gpu_mt19937_shard_offset(RowGenerator, oracle):
+    rs = np.random.RandomState(32)
+    snps, samples = random_case(rs, 156, 100)  # 39 rows per wave
+    whole, off, _ = _oracle_mt(oracle, snps, samples, 2024)
+    with RowGenerator(device=0, seed=2024, rng="mt19937") as g:
+        g.set_samples(samples)
+        g.set_snps(snps[78:], rng_row0=78)
+        t, _, _ = g.generate()
+    assert t.tobytes() == whole[int(off[78]):]

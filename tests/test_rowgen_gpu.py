@@ -126,7 +126,9 @@ def test_errors_are_reported_not_fatal(RowGenerator):
         with pytest.raises(capi.DnafError):
             g.ctx.generate(0, 2)
         with pytest.raises(capi.DnafError):
-            g.ctx.set_rng(capi.RNG_MT19937, 1)
+            g.ctx.set_rng(capi.RNG_MT19937, 2**32)  # numpy.random.seed accepts 0 .. 2^32-1 only
+        with pytest.raises(capi.DnafError):
+            g.ctx.set_rng(7, 1)
 
 
 def test_full_size_properties(RowGenerator):
