@@ -47,13 +47,19 @@ def parse_cmd_args(args):
     # --- extensions ---
     p.add_argument("--seed", type=int, help="RNG seed (default: wall clock HHMMSS, like the reference); also seeds "
                                             "python's `random` so that a run is reproducible")
-    p.add_argument("--rng", choices=["philox", "mt19937"], default="philox", help="row RNG (DESIGN.md section 2)")
+    p.add_argument("--rng", choices=["philox", "mt19937"], default="philox",
+                   help="row RNG: philox = counter-based Philox4x32-10 (default, fastest); mt19937 = numpy's legacy "
+                        "stream continued from the host side's numpy state, i.e. the numbers the reference itself "
+                        "would draw with the same seeds (DESIGN.md section 2)")
     p.add_argument("--devices", type=str, default="0", help="comma-separated GPU ids; SNP ranges are sharded over them")
     p.add_argument("--tile-rows", type=int, default=0, help="SNP rows generated per kernel launch (0 = auto)")
     p.add_argument("--threads", type=int, default=0, help="BGZF compression threads per shard (0 = auto)")
     p.add_argument("--host-bgzf", action="store_true",
                    help="compress on the host with zlib at level -z (like the reference) instead of the on-GPU BGZF "
                         "encoder, which ignores -z")
+    p.add_argument("--compat-chunk-restart", action="store_true",
+                   help="restart the random stream at every 1M-SNP work chunk like the reference does "
+                        "(pop_factory.py:402-411; only matters from 2M SNPs up)")
     p.add_argument("--compat-deleterious-file-bug", action="store_true",
                    help="keep the reference's behaviour for --deleterious_file: ids stay strings, so nothing is forced")
     return p.parse_args(args)
@@ -64,16 +70,27 @@ def _auto_tile_rows(n_samples, n_rows):
     return max(1, min(max(n_rows, 1), (512 << 20) // per_row))
 
 
-def _generate_shard(device, seed, rng, st, tb, row_lo, row_hi, tile_rows, sink, progress, host_bgzf):
+def reference_chunks(n):
+    """Row ranges of the reference's work chunks (output_vcf_population, pop_factory.py:402-411: int(n / 1e6) chunks,
+    split_list with round(), last chunk takes the remainder).  Its workers fork from the same parent state for every
+    chunk, so the random stream restarts at each chunk start."""
+    chunks = int(n / 1000000) or 1
+    size = round(n / chunks)
+    return [(i * size, n if i + 1 == chunks else (i + 1) * size) for i in range(chunks)]
+
+
+def _generate_shard(device, seed, rng, mt_state, st, tb, row_lo, row_hi, rng_row_lo, tile_rows, sink, progress, host_bgzf):
     """Rows [row_lo, row_hi) of the table on one GPU -> the BGZF sink, in order.  By default the text is
     compressed on the GPU and only BGZF members cross PCIe; with host_bgzf the text is copied out and
     compressed by the sink's zlib workers."""
     from .rowgen import RowGenerator
 
-    with RowGenerator(device=device, seed=seed, rng=rng) as gen:
+    with RowGenerator(device=device, seed=seed, rng=rng, mt_state=mt_state) as gen:
         gen.set_samples(st)
-        gen.set_snps(tb.slice(row_lo, row_hi), rng_row0=row_lo)
+        gen.set_snps(tb.slice(row_lo, row_hi), rng_row0=rng_row_lo)
         n = row_hi - row_lo
+        q = gen.row_quantum
+        tile_rows = max(q, tile_rows // q * q)
         for b in range(0, n, tile_rows):
             m = min(tile_rows, n - b)
             if host_bgzf:
@@ -85,7 +102,8 @@ def _generate_shard(device, seed, rng, st, tb, row_lo, row_hi, tile_rows, sink, 
             progress(m)
 
 
-def write_vcf(path, header, st, tb, seed, rng, devices, compresslevel, tile_rows=0, threads=0, host_bgzf=False):
+def write_vcf(path, header, st, tb, seed, rng, devices, compresslevel, tile_rows=0, threads=0, host_bgzf=False,
+              mt_state=None, chunk_restart=False):
     """population.vcf.gz = header + one body line per SNP (output_vcf_population, pop_factory.py:385-415).
     With several devices each GPU writes its contiguous SNP range to its own BGZF shard; shards are then
     concatenated (BGZF members are independent), ending with a single EOF block."""
@@ -106,15 +124,26 @@ def write_vcf(path, header, st, tb, seed, rng, devices, compresslevel, tile_rows
             print("%s Output %i/%i VCF lines." % (datetime.now().strftime("%Y-%m-%d %H:%M:%S"), done[0], n), flush=True)
 
     print("Outputing VCF lines", flush=True)
+    # units of work: (first row, end row, RNG row of the first row).  By default one stream covers the whole table;
+    # with chunk_restart the stream restarts at every reference work chunk, as the reference's does.
+    units = [(lo, hi, 0) for lo, hi in reference_chunks(n)] if chunk_restart else [(0, n, 0)]
     if len(devices) == 1:
         with bgzf.BgzfWriter(path, compresslevel=compresslevel, threads=threads) as f:
             f.write(header)
-            _generate_shard(devices[0], seed, rng, st, tb, 0, n, tile_rows, f, progress, host_bgzf)
+            for lo, hi, r0 in units:
+                _generate_shard(devices[0], seed, rng, mt_state, st, tb, lo, hi, r0, tile_rows, f, progress, host_bgzf)
     else:
+        from math import gcd
+
         from .sharding import shard_bounds
 
+        if chunk_restart:
+            raise SystemExit("--compat-chunk-restart is only supported on one device")
         G = len(devices)
         bounds = shard_bounds(n, G)
+        if rng == "mt19937" and len(st):  # shards must start on a wave boundary of the sequential stream
+            q = 156 // gcd(len(st), 156)
+            bounds = [min(n, (b + q - 1) // q * q) for b in bounds[:-1]] + [n]
         shard_paths = ["%s.shard%d" % (path, g) for g in range(G)]
         errors = []
 
@@ -124,7 +153,9 @@ def write_vcf(path, header, st, tb, seed, rng, devices, compresslevel, tile_rows
                     w = bgzf.BgzfWriter(fileobj=_NoClose(raw), compresslevel=compresslevel, threads=threads)
                     if g == 0:
                         w.write(header)
-                    _generate_shard(devices[g], seed, rng, st, tb, bounds[g], bounds[g + 1], tile_rows, w, progress, host_bgzf)
+                    if bounds[g + 1] > bounds[g]:
+                        _generate_shard(devices[g], seed, rng, mt_state, st, tb, bounds[g], bounds[g + 1], bounds[g], tile_rows, w,
+                                        progress, host_bgzf)
                     w.flush()  # no EOF block inside a shard
                     w.close_pool()
             except BaseException as e:  # surfaced in the parent, never swallowed
@@ -206,8 +237,14 @@ def generate_population(args):
     st = pop.build_samples(groups, args.control_size, args.size, args.male_odds, outdir, offset=args.offset or 0)
     header = pop.vcf_header(st.person_id)
     devices = [int(d) for d in args.devices.split(",") if d != ""]
+    mt_state = None
+    if args.rng == "mt19937":
+        # the reference's worker forks here and keeps drawing from the parent's numpy stream (pop_factory.py:432-434)
+        state = numpy.random.get_state()
+        mt_state = (state[1], int(state[2]))
     write_vcf(outdir + "population.vcf.gz", header, st, tb, seed, args.rng, devices, args.compression_level,
-              tile_rows=args.tile_rows, threads=args.threads, host_bgzf=args.host_bgzf)
+              tile_rows=args.tile_rows, threads=args.threads, host_bgzf=args.host_bgzf, mt_state=mt_state,
+              chunk_restart=args.compat_chunk_restart)
     print("Finished Generating Population in %0.4f secs." % (time.time() - t_start), flush=True)
     return outdir
 

@@ -125,6 +125,48 @@ def test_cli_end_to_end_matches_oracle(oracle, tmp_path):
     assert bgzf.block_sizes(str(out2 / "population.vcf.gz"))[-1] == 28
 
 
+def test_reference_chunk_ranges(cli):
+    # split_list semantics, common/snp.py:71-79 with chunks = int(n / 1e6) or 1 (pop_factory.py:407-410)
+    assert cli.reference_chunks(10) == [(0, 10)]
+    assert cli.reference_chunks(1999999) == [(0, 1999999)]
+    assert cli.reference_chunks(2000001) == [(0, 1000000), (1000000, 2000001)]
+    assert cli.reference_chunks(3500000) == [(0, 1166667), (1166667, 2333334), (2333334, 3500000)]
+
+
+@pytest.mark.gpu
+def test_cli_mt19937_continues_the_numpy_stream(oracle, tmp_path):
+    """--rng mt19937: the VCF body is what the reference's worker draws next from the host side's numpy stream.
+    The expected state is obtained by replaying the same feeder calls (they are pinned against the reference in
+    tests/test_population_host.py)."""
+    import random
+
+    import numpy
+
+    from dna_factory_amd import population as pop
+
+    out = tmp_path / "mt"
+    r = _run_cli(["-s", "30", "-c", "22", "-x", "700", "-f", "0.01", "--seed", "86399", "--rng", "mt19937",
+                  "--outdir", str(out), "--tile-rows", "90", "--devices", "0,0"])
+    assert r.returncode == 0, r.stderr
+    numpy.random.seed(86399)
+    random.seed(86399)
+    tb = pop.sort_snp_table(pop.generate_snp_table(700, min_maf=0.01))
+    groups = pop.pick_deleterious(tb, os.path.join(REPO, "deleterious.yml"))
+    pop.build_samples(groups, 22, 30, 0.5, str(tmp_path))
+    st = numpy.random.get_state()
+    snps = []
+    for line in gzip.open(out / "snps.json.gz", "rt"):
+        o = json.loads(line)
+        snps.append((o["id"], o["chromosome"], o["position"], list(o["tuples"].items())))
+    _, samples = _expected_body(str(out), 0, oracle)
+    rec = oracle.snp_records(snps)
+    sex, ctrl, off, ids = oracle.sample_arrays(samples)
+    want, _, _ = oracle.generate(rec, sex, ctrl, off, ids, rng_mode=oracle.RNG_MT19937,
+                                 mt_state=(st[1].astype(np.uint32), int(st[2])))
+    body = gzip.open(out / "population.vcf.gz", "rb").read().split(b"#CHROM", 1)[1].split(b"\n", 1)[1]
+    assert body == want
+
+
 @pytest.mark.gpu
 def test_cli_refuses_the_database_path(tmp_path):
     r = _run_cli(["-s", "1", "-c", "1", "-l", "--outdir", str(tmp_path / "x")])
