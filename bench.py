@@ -38,6 +38,8 @@ def parse_args():
     ap.add_argument("--seed", type=int, default=12345, help="row RNG seed")
     ap.add_argument("--table-seed", type=int, default=20261004, help="seed of the synthetic SNP / sample tables")
     ap.add_argument("--what", choices=["text+packed", "text", "packed"], default="text+packed")
+    ap.add_argument("--rng", choices=["philox", "mt19937"], default="philox",
+                    help="row RNG; mt19937 = numpy-compatible stream (tile rows are rounded down to its row quantum)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target duration of the CPU baseline sample (0 = skip)")
     ap.add_argument("--bgzf-tiles", type=int, default=2,
                     help="after the timed region, compress this many tiles with the on-GPU BGZF encoder and report "
@@ -170,8 +172,13 @@ def main():
     rs = np.random.RandomState(a.table_seed + 1000 * rank)
     tb = synthetic_snp_table(rows, a.min_maf, rs)
     st = synthetic_samples(S, rows, tb.snp_id, np.random.RandomState(a.table_seed))  # same samples on every rank
-    gen = RowGenerator(device=local_rank, seed=a.seed)
+    gen = RowGenerator(device=local_rank, seed=a.seed, rng=a.rng)
     gen.set_samples(st)
+    q = gen.row_quantum
+    a.tile_rows = max(q, a.tile_rows // q * q)
+    rows = max(a.tile_rows, rows // a.tile_rows * a.tile_rows)
+    if rows < len(tb):
+        tb = tb.slice(0, rows)
     gen.set_snps(tb, rng_row0=rank * rows)  # this rank's SNP range of the global table
     what = {"text+packed": capi.OUT_TEXT | capi.OUT_PACKED, "text": capi.OUT_TEXT, "packed": capi.OUT_PACKED}[a.what]
     n_tiles = max(1, rows // a.tile_rows)
@@ -247,12 +254,12 @@ def main():
             "config": {"workload": "BASELINE config 3: 10k cases + 10k controls x 5M SNPs, -f 0.01 (per GPU), "
                                    "streamed in row tiles; outputs resident in HBM",
                        "samples": S, "tile_rows": a.tile_rows, "table_rows_per_gpu": rows, "min_maf": a.min_maf,
-                       "outputs": a.what, "rng": "philox4x32-10", "seed": a.seed, "table_seed": a.table_seed,
+                       "outputs": a.what, "rng": "philox4x32-10" if a.rng == "philox" else "mt19937 (numpy legacy)", "seed": a.seed, "table_seed": a.table_seed,
                        "sharding": "SNP-range per GPU, no collective"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "bytes_per_launch": bytes_per_launch, "kernel_ms_mean": mean_kernel_s * 1e3,
-                         "launches_timed": n_rec, "kernel": "rowgen_kernel",
+                         "launches_timed": n_rec, "kernel": "rowgen_kernel" if a.rng == "philox" else "mt_rowgen_kernel (+ mt_jump_kernel)",
                          "draws_per_s": 2.0 * S * a.tile_rows / mean_kernel_s},
         }
         if a.bgzf_tiles > 0 and (what & capi.OUT_TEXT):

@@ -58,12 +58,22 @@ __global__ __launch_bounds__(640) void mt_jump_kernel(const uint32_t* src, const
     }
     if (t < MTN) {
         uint32_t acc = 0;
+        const uint32_t* xt = x + t + 1u;
         for (uint32_t w = 0; w < 312u; ++w) {
-            uint64_t bits = poly[w]; // wave-uniform
+            uint64_t bits = poly[w]; // wave-uniform: the positions are scalar, the loads are independent
+            const uint32_t* xw = xt + 64u * w;
             while (bits) {
-                const uint32_t i = 64u * w + (uint32_t)__builtin_ctzll(bits);
-                bits &= bits - 1;
-                acc ^= x[i + t + 1u];
+                uint32_t idx[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    idx[u] = bits ? (uint32_t)__builtin_ctzll(bits) : 0xFFFFFFFFu;
+                    bits &= bits - 1; // stays 0 once empty
+                }
+                uint32_t val[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) val[u] = idx[u] != 0xFFFFFFFFu ? xw[idx[u]] : 0u;
+#pragma unroll
+                for (int u = 0; u < 8; ++u) acc ^= val[u];
             }
         }
         dst[(uint64_t)j * MTN + t] = acc;
@@ -87,22 +97,47 @@ __device__ __forceinline__ uint32_t pick53(uint64_t r, uint64_t t0, uint64_t t1,
 
 __device__ __forceinline__ uint64_t roll53(uint32_t a, uint32_t b) { return ((uint64_t)(a >> 5) << 26) | (uint64_t)(b >> 6); }
 
-// One wave: regenerate the state in place (the sequential algorithm's in-place update, 64 lanes at a
-// time; every step reads only words the previous steps have finished writing or not yet touched).
-__device__ __forceinline__ void mt_wave_regenerate(uint32_t* st, uint32_t lane)
+// One wave: the next block.  The state is regenerated in place in the three dependent phases of the
+// recurrence (words 0..226 need only old words; 227..453 need the new words 0..226; 454..623 need the
+// new words 227..396, and word 623 the new word 0).  Inside a phase nothing depends on anything else
+// written in that phase, so all of a phase's LDS reads are issued before its writes: three latency
+// exposures per block instead of ten.  Each new word is also tempered into the output ring at
+// ring[(head + i) mod MT_RING].
+template <uint32_t LO, uint32_t HI>
+__device__ __forceinline__ void mt_wave_phase(uint32_t* st, uint32_t* ring, uint32_t head, uint32_t lane)
 {
-    for (uint32_t i0 = 0; i0 < MTN; i0 += 64u) {
-        const uint32_t i = i0 + lane;
-        uint32_t v = 0;
-        if (i < MTN) {
+    constexpr uint32_t STEPS = (HI - LO + 63u) / 64u;
+    uint32_t v[STEPS];
+#pragma unroll
+    for (uint32_t s = 0; s < STEPS; ++s) {
+        const uint32_t i = LO + 64u * s + lane;
+        v[s] = 0;
+        if (i < HI) {
             const uint32_t i1 = i + 1u == MTN ? 0u : i + 1u;
             const uint32_t im = i + MTM < MTN ? i + MTM : i + MTM - MTN;
-            v = st[im] ^ mt_twist(st[i], st[i1]);
+            v[s] = st[im] ^ mt_twist(st[i], st[i1]);
         }
-        __builtin_amdgcn_wave_barrier();
-        if (i < MTN) st[i] = v;
-        __builtin_amdgcn_wave_barrier();
     }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (uint32_t s = 0; s < STEPS; ++s) {
+        const uint32_t i = LO + 64u * s + lane;
+        if (i < HI) {
+            st[i] = v[s];
+            uint32_t h = head + i;
+            h = h >= MT_RING ? h - MT_RING : h;
+            ring[h] = mt_temper(v[s]);
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
+__device__ __forceinline__ void mt_wave_next_block(uint32_t* st, uint32_t* ring, uint32_t head, uint32_t lane)
+{
+    mt_wave_phase<0, 227>(st, ring, head, lane);
+    mt_wave_phase<227, 454>(st, ring, head, lane);
+    mt_wave_phase<454, 623>(st, ring, head, lane);
+    mt_wave_phase<623, 624>(st, ring, head, lane); // needs the new word 0
 }
 
 template <bool TEXT, bool PACKED>
@@ -146,12 +181,7 @@ __global__ __launch_bounds__(64) void mt_rowgen_kernel(const MtGenParams mp)
         for (uint32_t gb = 0; gb < G; gb += 64u) {
             const uint32_t need = min(1024u, row_words - consumed);
             while (avail < need) { // wave-uniform
-                mt_wave_regenerate(st, lane);
-                for (uint32_t i = lane; i < MTN; i += 64u) {
-                    uint32_t h = head + i;
-                    if (h >= MT_RING) h -= MT_RING;
-                    ring[h] = mt_temper(st[i]);
-                }
+                mt_wave_next_block(st, ring, head, lane);
                 head += MTN;
                 if (head >= MT_RING) head -= MT_RING;
                 avail += MTN;
@@ -177,7 +207,6 @@ __global__ __launch_bounds__(64) void mt_rowgen_kernel(const MtGenParams mp)
                     for (int k = 0; k < 4; ++k)
                         if ((f >> k) & 1u) a[k] = b[k] = 1u;
                 }
-                const uint32_t male = p.male_nib[g];
                 uint32_t pk = 0;
                 if (cls == 0u && 4u * g + 4u < S) { // complete autosome group that does not hold the row's last sample
                     if (TEXT) {
@@ -188,6 +217,7 @@ __global__ __launch_bounds__(64) void mt_rowgen_kernel(const MtGenParams mp)
                     pk = nz(a[0]) | nz(b[0]) << 1 | nz(a[1]) << 2 | nz(b[1]) << 3 | nz(a[2]) << 4 | nz(b[2]) << 5 |
                          nz(a[3]) << 6 | nz(b[3]) << 7;
                 } else {
+                    const uint32_t male = p.male_nib[g]; // only the sex-chromosome rules need it
                     uint8_t* dst = cells + (cls == 0u ? 16ull * g : (cls == 1u ? (uint64_t)p.xoff[g] : 8ull * g));
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
