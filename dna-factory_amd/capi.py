@@ -33,6 +33,7 @@ SYMBOLS = [
     "dnaf_sync", "dnaf_last_generate_ms", "dnaf_timing_begin", "dnaf_timing_end", "dnaf_read_text", "dnaf_read_packed", "dnaf_device_buffers",
     "dnaf_format_prefixes", "dnaf_bgzf_compress", "dnaf_read_bgzf", "dnaf_last_bgzf_ms",
     "dnaf_bgzf_tables_from_histogram", "dnaf_set_mt_state", "dnaf_mt_jump_host", "dnaf_mt_characteristic_polynomial",
+    "dnaf_fetch_bgzf", "dnaf_fetch_text",
 ]
 
 
@@ -89,6 +90,8 @@ def _load():
         "dnaf_last_bgzf_ms": (ci, [vp, vp]),
         "dnaf_bgzf_tables_from_histogram": (ci, [vp, vp, u64, vp, u64, vp]),
         "dnaf_set_mt_state": (ci, [vp, vp, u32, u64]),
+        "dnaf_fetch_bgzf": (ci, [vp, vp, vp]),
+        "dnaf_fetch_text": (ci, [vp, vp, vp]),
         "dnaf_mt_jump_host": (ci, [vp, u64, vp]),
         "dnaf_mt_characteristic_polynomial": (ci, [vp, vp]),
     }
@@ -266,6 +269,22 @@ class Context:
         got = ctypes.c_uint64(0)
         self._check(lib.dnaf_read_bgzf(self._h, ptr(buf), n_bytes, ctypes.byref(got)))
         return buf[: got.value]
+
+    def _fetch(self, fn):
+        host = ctypes.c_void_p(None)
+        n = ctypes.c_uint64(0)
+        self._check(fn(self._h, ctypes.byref(host), ctypes.byref(n)))
+        if n.value == 0:
+            return np.empty(0, dtype=np.uint8)
+        # a view of the library's pinned buffer: valid until the next fetch on this context
+        return np.ctypeslib.as_array(ctypes.cast(host, ctypes.POINTER(ctypes.c_uint8)), shape=(n.value,))
+
+    def fetch_bgzf(self):
+        """The last compressed range as a numpy view of pinned host memory (no extra copy)."""
+        return self._fetch(lib.dnaf_fetch_bgzf)
+
+    def fetch_text(self):
+        return self._fetch(lib.dnaf_fetch_text)
 
     def last_bgzf_ms(self):
         v = ctypes.c_float(0)

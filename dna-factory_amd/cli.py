@@ -83,6 +83,7 @@ def _generate_shard(device, seed, rng, mt_state, st, tb, row_lo, row_hi, rng_row
     """Rows [row_lo, row_hi) of the table on one GPU -> the BGZF sink, in order.  By default the text is
     compressed on the GPU and only BGZF members cross PCIe; with host_bgzf the text is copied out and
     compressed by the sink's zlib workers."""
+    from . import capi
     from .rowgen import RowGenerator
 
     with RowGenerator(device=device, seed=seed, rng=rng, mt_state=mt_state) as gen:
@@ -93,12 +94,12 @@ def _generate_shard(device, seed, rng, mt_state, st, tb, row_lo, row_hi, rng_row
         tile_rows = max(q, tile_rows // q * q)
         for b in range(0, n, tile_rows):
             m = min(tile_rows, n - b)
+            gen.ctx.generate(b, m, capi.OUT_TEXT)
             if host_bgzf:
-                text, _, _ = gen.generate(b, m, text=True, packed=False)
-                sink.write(text)
+                sink.write(gen.ctx.fetch_text())
             else:
-                blob, _ = gen.generate_bgzf(b, m, reuse_tables=b > 0)
-                sink.write_members(blob)
+                gen.ctx.bgzf_compress(reuse_tables=b > 0)
+                sink.write_members(gen.ctx.fetch_bgzf())  # pinned staging buffer: consumed before the next fetch
             progress(m)
 
 

@@ -91,6 +91,10 @@ struct dnaf_ctx {
     hipEvent_t zev[2] = {nullptr, nullptr};
     float bgzf_ms = 0.f;
 
+    // pinned host staging for device -> host copies at PCIe rate
+    void* h_pinned = nullptr;
+    uint64_t pinned_cap = 0;
+
     // tuning
     uint32_t seg_iters = 32;
 };
@@ -178,6 +182,7 @@ int dnaf_destroy(dnaf_ctx* c)
     dev_free(c->d_prefix);
     dev_free(c->d_text);
     dev_free(c->d_packed);
+    if (c->h_pinned) (void)hipHostFree(c->h_pinned);
     dev_free(c->d_thr53);
     dev_free(c->d_mt_base);
     dev_free(c->d_mt_states);
@@ -849,6 +854,42 @@ int dnaf_read_bgzf(dnaf_ctx* c, void* dst, uint64_t dst_cap, uint64_t* n_bytes)
     if (c->bgzf_bytes) HIP_TRY(c, hipMemcpyAsync(dst, c->d_bgzf, c->bgzf_bytes, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return DNAF_OK;
+}
+
+// Copy `n` bytes from device memory into the context's pinned staging buffer (grown on demand).
+static int fetch_pinned(dnaf_ctx* c, const void* d_src, uint64_t n, const void** host)
+{
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (n > c->pinned_cap) {
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        if (c->h_pinned) (void)hipHostFree(c->h_pinned);
+        c->h_pinned = nullptr;
+        c->pinned_cap = 0;
+        const uint64_t want = n + n / 4 + 4096;
+        HIP_TRY(c, hipHostMalloc(&c->h_pinned, want, hipHostMallocDefault));
+        c->pinned_cap = want;
+    }
+    if (n) HIP_TRY(c, hipMemcpyAsync(c->h_pinned, d_src, n, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    *host = c->h_pinned;
+    return DNAF_OK;
+}
+
+int dnaf_fetch_bgzf(dnaf_ctx* c, const void** host, uint64_t* n_bytes)
+{
+    if (!c || !host) return DNAF_ERR_BAD_ARG;
+    if (!c->have_bgzf) return fail(c, DNAF_ERR_STATE, "dnaf_fetch_bgzf: nothing was compressed");
+    if (n_bytes) *n_bytes = c->bgzf_bytes;
+    return fetch_pinned(c, c->d_bgzf, c->bgzf_bytes, host);
+}
+
+int dnaf_fetch_text(dnaf_ctx* c, const void** host, uint64_t* n_bytes)
+{
+    if (!c || !host) return DNAF_ERR_BAD_ARG;
+    if (!c->have_output || !(c->last_what & DNAF_OUT_TEXT)) return fail(c, DNAF_ERR_STATE, "dnaf_fetch_text: no text was generated");
+    const uint64_t n = c->h_text_off[(size_t)(c->last_begin + c->last_rows)] - c->h_text_off[(size_t)c->last_begin];
+    if (n_bytes) *n_bytes = n;
+    return fetch_pinned(c, c->d_text, n, host);
 }
 
 int dnaf_last_bgzf_ms(dnaf_ctx* c, float* ms)

@@ -155,6 +155,11 @@ int dnaf_device_buffers(dnaf_ctx* ctx, void** d_text, uint64_t* text_bytes, void
 #define DNAF_BGZF_REUSE_TABLES 1u
 int dnaf_bgzf_compress(dnaf_ctx* ctx, uint32_t flags, uint64_t* n_bytes);
 int dnaf_read_bgzf(dnaf_ctx* ctx, void* dst, uint64_t dst_cap, uint64_t* n_bytes);
+/* The same data through the context's pinned staging buffer (DMA at PCIe rate instead of a pageable
+ * copy): *host points at n_bytes bytes owned by the library, valid until the next dnaf_fetch_* /
+ * dnaf_destroy on this context.  Synchronises. */
+int dnaf_fetch_bgzf(dnaf_ctx* ctx, const void** host, uint64_t* n_bytes);
+int dnaf_fetch_text(dnaf_ctx* ctx, const void** host, uint64_t* n_bytes);
 /* Summed device time of the encoder's kernels in the last dnaf_bgzf_compress (HIP events). */
 int dnaf_last_bgzf_ms(dnaf_ctx* ctx, float* ms);
 /* Host-only helper: the encoder's code tables for a token histogram (256 literal counts, 256 counts
