@@ -152,12 +152,20 @@ def main():
     if world != max(a.gpus, 1) and world > 1:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (a.gpus, world))
     dist = None
+    # rehearsal knobs (tests on a one-GPU box only): DNAF_BENCH_BACKEND=gloo keeps the collectives on the CPU and
+    # DNAF_BENCH_SHARE_GPU=1 lets several ranks share GPU 0; the driver's runs use neither.
+    backend = os.environ.get("DNAF_BENCH_BACKEND", "nccl")
+    if os.environ.get("DNAF_BENCH_SHARE_GPU"):
+        local_rank = 0
     if world > 1:
         import torch
         import torch.distributed as dist
 
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     import __graft_entry__ as ge
 
@@ -215,7 +223,7 @@ def main():
     kern_ms, n_rec, n_launch = gen.ctx.timing_end()
     from dna_factory_amd.sharding import max_over_ranks
 
-    elapsed = max_over_ranks(t1 - t0, dist, "cuda" if dist is not None else None)
+    elapsed = max_over_ranks(t1 - t0, dist, "cuda" if (dist is not None and backend == "nccl") else None)
 
     if rank == 0:
         # algorithmic bytes of one launch: packed row + text row + 32-byte SNP record, per row

@@ -70,13 +70,18 @@ def _auto_tile_rows(n_samples, n_rows):
     return max(1, min(max(n_rows, 1), (512 << 20) // per_row))
 
 
-def reference_chunks(n):
-    """Row ranges of the reference's work chunks (output_vcf_population, pop_factory.py:402-411: int(n / 1e6) chunks,
-    split_list with round(), last chunk takes the remainder).  Its workers fork from the same parent state for every
-    chunk, so the random stream restarts at each chunk start."""
-    chunks = int(n / 1000000) or 1
+def split_ranges(n, chunks):
+    """Index ranges of split_list(l, chunks) for len(l) == n (common/snp.py:71-79): chunk size round(n / chunks),
+    the last chunk takes the remainder."""
     size = round(n / chunks)
     return [(i * size, n if i + 1 == chunks else (i + 1) * size) for i in range(chunks)]
+
+
+def reference_chunks(n):
+    """Row ranges of the reference's work chunks (output_vcf_population, pop_factory.py:402-411: int(n / 1e6) chunks
+    of split_list).  Its workers fork from the same parent state for every chunk, so the random stream restarts at
+    each chunk start."""
+    return split_ranges(n, int(n / 1000000) or 1)
 
 
 def _generate_shard(device, seed, rng, mt_state, st, tb, row_lo, row_hi, rng_row_lo, tile_rows, sink, progress, host_bgzf):

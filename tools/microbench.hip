@@ -57,6 +57,20 @@ __global__ __launch_bounds__(256) void k_store16(uint8_t* dst, uint64_t bytes_pe
     }
 }
 
+typedef uint32_t u32x4_a1 __attribute__((ext_vector_type(4), aligned(1)));
+// same as k_store16 with non-temporal stores (global_store_dwordx4 ... nt)
+__global__ __launch_bounds__(256) void k_store16_nt(uint8_t* dst, uint64_t bytes_per_wave, uint32_t m)
+{
+    const uint32_t lane = threadIdx.x & 63;
+    const uint64_t wave = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    uint8_t* p = dst + wave * bytes_per_wave + m + lane * 16;
+    u32x4_a1 v = {0x092F3030u, 0x092F3031u, 0x092F3130u, 0x092F3131u};
+    for (uint64_t o = 0; o + 1024 <= bytes_per_wave - 16; o += 1024) {
+        v.x += lane;
+        __builtin_nontemporal_store(v, reinterpret_cast<u32x4_a1*>(p + o));
+    }
+}
+
 __global__ __launch_bounds__(256) void k_store4(uint8_t* dst, uint64_t bytes_per_wave, uint32_t m)
 {
     const uint32_t lane = threadIdx.x & 63;
@@ -114,6 +128,18 @@ int main()
             }
             double bytes = (double)waves * ((bpw - 16) / 1024) * 1024;
             printf("store16 bytes/wave=%llu misalign=%2u: %.3f ms  %.1f GB/s\n", (unsigned long long)bpw, m, ms, bytes / (ms * 1e-3) / 1e9);
+        }
+    }
+    {
+        const uint64_t bpw = 32768, waves = total / bpw; const uint32_t blocks = (uint32_t)(waves / 4);
+        for (uint32_t m : {0u, 4u, 5u}) {
+            for (int rep = 0; rep < 2; ++rep) {
+                CK(hipEventRecord(e0));
+                hipLaunchKernelGGL(k_store16_nt, dim3(blocks), dim3(256), 0, 0, d_buf, bpw, m);
+                CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms, e0, e1));
+            }
+            double bytes = (double)waves * ((bpw - 16) / 1024) * 1024;
+            printf("store16nt bytes/wave=%llu misalign=%2u: %.3f ms  %.1f GB/s\n", (unsigned long long)bpw, m, ms, bytes / (ms * 1e-3) / 1e9);
         }
     }
     {
