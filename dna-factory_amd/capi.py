@@ -33,7 +33,7 @@ SYMBOLS = [
     "dnaf_sync", "dnaf_last_generate_ms", "dnaf_timing_begin", "dnaf_timing_end", "dnaf_read_text", "dnaf_read_packed", "dnaf_device_buffers",
     "dnaf_format_prefixes", "dnaf_bgzf_compress", "dnaf_read_bgzf", "dnaf_last_bgzf_ms",
     "dnaf_bgzf_tables_from_histogram", "dnaf_set_mt_state", "dnaf_mt_jump_host", "dnaf_mt_characteristic_polynomial",
-    "dnaf_fetch_bgzf", "dnaf_fetch_text",
+    "dnaf_fetch_bgzf", "dnaf_fetch_text", "dnaf_read_text_range",
 ]
 
 
@@ -92,6 +92,7 @@ def _load():
         "dnaf_set_mt_state": (ci, [vp, vp, u32, u64]),
         "dnaf_fetch_bgzf": (ci, [vp, vp, vp]),
         "dnaf_fetch_text": (ci, [vp, vp, vp]),
+        "dnaf_read_text_range": (ci, [vp, u64, u64, vp]),
         "dnaf_mt_jump_host": (ci, [vp, u64, vp]),
         "dnaf_mt_characteristic_polynomial": (ci, [vp, vp]),
     }
@@ -250,6 +251,11 @@ class Context:
         got = ctypes.c_uint64(0)
         self._check(lib.dnaf_read_text(self._h, ptr(buf), n_bytes, ctypes.byref(got)))
         return buf[: got.value]
+
+    def read_text_range(self, byte_begin, n_bytes):
+        buf = np.empty(max(n_bytes, 1), dtype=np.uint8)
+        self._check(lib.dnaf_read_text_range(self._h, int(byte_begin), int(n_bytes), ptr(buf)))
+        return buf[:n_bytes]
 
     def read_packed(self, n_rows, words_per_row):
         buf = np.empty((n_rows, words_per_row), dtype=np.uint32)

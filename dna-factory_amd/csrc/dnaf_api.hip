@@ -724,6 +724,19 @@ int dnaf_read_text(dnaf_ctx* c, void* dst, uint64_t dst_cap, uint64_t* n_bytes)
     return DNAF_OK;
 }
 
+int dnaf_read_text_range(dnaf_ctx* c, uint64_t byte_begin, uint64_t n_bytes, void* dst)
+{
+    if (!c) return DNAF_ERR_BAD_ARG;
+    if (!c->have_output || !(c->last_what & DNAF_OUT_TEXT)) return fail(c, DNAF_ERR_STATE, "dnaf_read_text_range: no text was generated");
+    const uint64_t n = c->h_text_off[(size_t)(c->last_begin + c->last_rows)] - c->h_text_off[(size_t)c->last_begin];
+    if (byte_begin > n || n_bytes > n - byte_begin) return fail(c, DNAF_ERR_BAD_ARG, "dnaf_read_text_range: [%llu,+%llu) outside the %llu bytes generated", (unsigned long long)byte_begin, (unsigned long long)n_bytes, (unsigned long long)n);
+    if (n_bytes && !dst) return fail(c, DNAF_ERR_BAD_ARG, "dnaf_read_text_range: dst is NULL");
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (n_bytes) HIP_TRY(c, hipMemcpyAsync(dst, c->d_text + byte_begin, n_bytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return DNAF_OK;
+}
+
 int dnaf_read_packed(dnaf_ctx* c, uint32_t* dst, uint64_t dst_cap_words, uint64_t* n_words)
 {
     if (!c) return DNAF_ERR_BAD_ARG;

@@ -142,6 +142,8 @@ int dnaf_timing_end(dnaf_ctx* ctx, double* total_ms, uint64_t* n_recorded, uint6
  * text: exactly dnaf_text_bytes() bytes; packed: n_rows*ceil(S/16) u32. */
 int dnaf_read_text(dnaf_ctx* ctx, void* dst, uint64_t dst_cap, uint64_t* n_bytes);
 int dnaf_read_packed(dnaf_ctx* ctx, uint32_t* dst, uint64_t dst_cap_words, uint64_t* n_words);
+/* Bytes [byte_begin, byte_begin + n_bytes) of the last generated text (consumers that stream a tile out in pieces). */
+int dnaf_read_text_range(dnaf_ctx* ctx, uint64_t byte_begin, uint64_t n_bytes, void* dst);
 
 /* Device pointers of the last generated range, for consumers that stay on
  * the GPU (valid until the next dnaf_generate / dnaf_destroy). */

@@ -168,3 +168,33 @@ def test_full_size_properties(RowGenerator):
         ctrl = slice(0, S // 2)
         alt_freq[j] = (a[ctrl].sum() + b[ctrl].sum()) / S
         assert abs(alt_freq[j] - maf[j]) < 6 * np.sqrt(maf[j] * (1 - maf[j]) / S) + 1e-9
+
+
+def test_tile_larger_than_4_gib(RowGenerator, oracle):
+    """One launch whose text exceeds 2^32 bytes: the rows at the far end (64-bit offsets) still match the oracle."""
+    from dna_factory_amd.tables import SampleTable, SnpTable
+
+    S, n = 20000, 56000  # 56,000 rows x ~80 KB = 4.5 GB
+    rs = np.random.RandomState(77)
+    flags = (rs.rand(S) <= 0.5).astype(np.uint8) | (np.arange(S) < S // 2).astype(np.uint8) * 2
+    st = SampleTable(flags)
+    maf = 0.005 * rs.randint(2, 100, n)
+    cum = np.ones((n, 4))
+    cum[:, 0] = 1 - maf
+    chrom = np.where(np.arange(n) % 50 == 7, b"X", b"3").astype("S2")
+    tb = SnpTable(np.arange(1, n + 1), chrom, np.arange(n) * 10 + 1, np.full(n, b"A", dtype="S1"),
+                  np.full(n, b"G", dtype="S1"), np.full(n, 2, np.uint8), cum)
+    sex, ctrl, doff, dids = oracle.sample_arrays_from_table(st.flags, st.forced_ids, st.carrier_off, st.carrier_idx)
+    with RowGenerator(device=0, seed=9) as g:
+        g.set_samples(st)
+        g.set_snps(tb)
+        g.ctx.generate(0, n, 1 | 2)
+        off = g.ctx.row_offsets(0, n)
+        assert int(off[n]) > 2**32
+        packed_tail = None
+        for b in (0, n // 2, n - 48):
+            text = g.ctx.read_text_range(int(off[b]), int(off[b + 48] - off[b]))
+            want, _, want_packed = oracle.generate(oracle.table_records(tb, b, b + 48), sex, ctrl, doff, dids, seed=9, rng_row0=b)
+            assert text.tobytes() == want
+        packed = g.ctx.read_packed(n, g.words_per_row)
+        assert np.array_equal(packed[n - 48:], want_packed)
