@@ -2,7 +2,7 @@
 // deflate "dynamic" block, its header bit string, and the CRC-32 combination constants.
 //
 // The reference writes population.vcf.gz through Bio.bgzf.BgzfWriter (pop_factory.py:403, :449), i.e.
-// zlib on the host.  Here the text never leaves the GPU uncompressed: every 64,512 input bytes become
+// zlib on the host.  Here the text never leaves the GPU uncompressed: every 61,440 input bytes become
 // one BGZF member encoded by one workgroup (bgzf_kernels.hip.h).  The token alphabet is deliberately
 // small -- literals and matches at distance 4 only (VCF GT cells repeat with period 4, or 2 for
 // haploid cells, which also has period 4) -- so one Huffman table per tile, built here from a sampled
@@ -17,7 +17,7 @@
 
 namespace dnaf {
 
-constexpr uint32_t BGZF_IN = 64512;   // input bytes per BGZF block = 1008 threads x 64 bytes
+constexpr uint32_t BGZF_IN = 61440;   // input bytes per BGZF block = 960 threads x 64 bytes
 constexpr uint32_t BGZF_CHUNK = 64;   // bytes tokenised by one thread
 constexpr uint32_t BGZF_NLIT = 286;   // literal/length symbols 0..285
 constexpr uint32_t BGZF_HDR_WORDS = 48;

@@ -1,6 +1,6 @@
 // bgzf_kernels.hip.h -- GPU BGZF (blocked gzip) encoder for the VCF text stream (gfx950).
 //
-// One 1024-thread workgroup encodes one BGZF member from 64,512 input bytes; 1008 of its threads own
+// One 1024-thread workgroup encodes one BGZF member from 61,440 input bytes; 960 of its threads own
 // a 64-byte chunk each.  Tokens are literals and matches at distance 4 only: byte i matches when it
 // equals byte i-4 of the same block (GT cells repeat with period 4; haploid cells with period 2).
 // Runs of matching bytes never cross a thread's chunk, so a chunk's 64 match bits live in one 64-bit
@@ -26,9 +26,10 @@ namespace dnaf {
 
 constexpr uint32_t BGZF_THREADS = 1024;
 constexpr uint32_t BGZF_WAVES = BGZF_THREADS / 64;
-constexpr uint32_t BGZF_ACTIVE = BGZF_IN / BGZF_CHUNK; // 1008 threads own a chunk
+constexpr uint32_t BGZF_ACTIVE = BGZF_IN / BGZF_CHUNK; // 960 threads own a chunk
 constexpr uint32_t BGZF_CHUNK_WORDS = BGZF_CHUNK / 4;  // 16
-constexpr uint32_t BGZF_LDS_OUT = 32768;               // bytes of LDS for one block's deflate body
+constexpr uint32_t BGZF_OUT_SMALL = 12288;             // LDS bytes for a member's deflate body: two workgroups per CU
+constexpr uint32_t BGZF_OUT_LARGE = 32768;             // ... for the members that compress worse (one workgroup per CU)
 constexpr uint32_t BGZF_MEMBER_OVERHEAD = 18 + 8;      // gzip header with BC field + CRC32 + ISIZE
 static_assert(BGZF_CHUNK == 64, "a chunk's match bits must fit one 64-bit register");
 static_assert(BGZF_ACTIVE * BGZF_CHUNK == BGZF_IN && BGZF_ACTIVE <= BGZF_THREADS, "chunking must tile the block");
@@ -40,7 +41,10 @@ struct BgzfParams {
     uint32_t sample_step;    // bgzf_hist: encode every sample_step-th block
     const BgzfTables* tables;
     uint32_t* hist;          // [256 literals][256 match lengths][1 eob]
-    uint32_t* sizes;         // [n_blocks] member size in bytes; bit 31 set = stored block
+    uint32_t* sizes;         // [n_blocks] member size in bytes; bit 31 = stored block, bit 30 = needs the large buffer
+    uint16_t* thread_bits;   // [n_blocks][BGZF_THREADS] deflate bits each thread's chunk encodes to (bgzf_size -> bgzf_encode)
+    uint32_t* crcs;          // [n_blocks] CRC-32 of each block's input (bgzf_size -> bgzf_encode)
+    uint32_t* large_list;    // [0] = number of members that need the large buffer, [1..] their block indices
     const uint64_t* offsets; // [n_blocks+1] exclusive scan of sizes
     uint8_t* out;
 };
@@ -240,62 +244,6 @@ __global__ __launch_bounds__(BGZF_THREADS) void bgzf_hist(const BgzfParams p)
     if (tid < 513 && h[tid]) atomicAdd(&p.hist[tid], h[tid]);
 }
 
-__device__ __forceinline__ void load_code_table(const BgzfParams& p, uint32_t* tab)
-{
-    if (threadIdx.x < 256) tab[threadIdx.x] = p.tables->lit[threadIdx.x];
-    else if (threadIdx.x < 512) tab[threadIdx.x] = p.tables->match[threadIdx.x - 256];
-}
-
-__global__ __launch_bounds__(BGZF_THREADS) void bgzf_size(const BgzfParams p)
-{
-    __shared__ uint32_t in_lds[BGZF_LDS_IN_WORDS];
-    __shared__ uint32_t tab[512];
-    __shared__ uint32_t scratch[BGZF_WAVES];
-    const uint32_t b = blockIdx.x, tid = threadIdx.x;
-    load_code_table(p, tab);
-    const uint32_t N = block_len(p, b);
-    stage_block(p.text + (uint64_t)b * BGZF_IN, N, in_lds);
-    __syncthreads();
-    const uint32_t c0 = tid * BGZF_CHUNK;
-    uint32_t bits = 0;
-    if (c0 < N) {
-        const uint32_t len = min(BGZF_CHUNK, N - c0);
-        const ChunkTokens t = chunk_tokens<false>(in_lds, tid, len, nullptr, nullptr);
-        CountSink s{0};
-        walk_tokens(t, reinterpret_cast<const uint8_t*>(in_lds + tid * (BGZF_CHUNK_WORDS + 1u)), tab, s);
-        bits = s.bits;
-    }
-    uint32_t total;
-    block_exclusive_scan(bits, scratch, &total);
-    if (tid == 0) {
-        const uint32_t body_bits = p.tables->hdr_nbits + total + (p.tables->eob & 31u);
-        const uint32_t body = (body_bits + 7u) >> 3;
-        const uint32_t stored = N + 5u;
-        if (body > BGZF_LDS_OUT || body >= stored) p.sizes[b] = (stored + BGZF_MEMBER_OVERHEAD) | 0x80000000u;
-        else p.sizes[b] = body + BGZF_MEMBER_OVERHEAD;
-    }
-}
-
-// exclusive scan of the member sizes: one workgroup, sequential over slices (n_blocks is a few 10^5)
-__global__ __launch_bounds__(1024) void bgzf_scan(const uint32_t* sizes, uint32_t n, uint64_t* offsets)
-{
-    __shared__ uint64_t part[1024];
-    const uint32_t per = (n + 1023u) / 1024u;
-    const uint32_t lo = min(n, threadIdx.x * per), hi = min(n, lo + per);
-    uint64_t s = 0;
-    for (uint32_t i = lo; i < hi; ++i) s += sizes[i] & 0x7FFFFFFFu;
-    part[threadIdx.x] = s;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        uint64_t run = 0;
-        for (uint32_t i = 0; i < 1024; ++i) { const uint64_t t = part[i]; part[i] = run; run += t; }
-        offsets[n] = run;
-    }
-    __syncthreads();
-    uint64_t run = part[threadIdx.x];
-    for (uint32_t i = lo; i < hi; ++i) { offsets[i] = run; run += sizes[i] & 0x7FFFFFFFu; }
-}
-
 __device__ __forceinline__ uint32_t crc_mulmod(uint32_t a, uint32_t b)
 {
     uint32_t m = 1u << 31, r = 0;
@@ -307,23 +255,115 @@ __device__ __forceinline__ uint32_t crc_mulmod(uint32_t a, uint32_t b)
     return r;
 }
 
-__global__ __launch_bounds__(BGZF_THREADS) void bgzf_encode(const BgzfParams p)
+__device__ __forceinline__ void load_code_table(const BgzfParams& p, uint32_t* tab)
+{
+    if (threadIdx.x < 256) tab[threadIdx.x] = p.tables->lit[threadIdx.x];
+    else if (threadIdx.x < 512) tab[threadIdx.x] = p.tables->match[threadIdx.x - 256];
+}
+
+__global__ __launch_bounds__(BGZF_THREADS) void bgzf_size(const BgzfParams p)
 {
     __shared__ uint32_t in_lds[BGZF_LDS_IN_WORDS];
-    __shared__ uint32_t outbuf[BGZF_LDS_OUT / 4];
     __shared__ uint32_t tab[512];
     __shared__ uint32_t crc_tab[4][256];
     __shared__ uint32_t scratch[BGZF_WAVES];
     const uint32_t b = blockIdx.x, tid = threadIdx.x;
+    load_code_table(p, tab);
+    crc_tab[tid >> 8][tid & 255u] = p.tables->crc_table[tid >> 8][tid & 255u];
+    const uint32_t N = block_len(p, b);
+    stage_block(p.text + (uint64_t)b * BGZF_IN, N, in_lds);
+    __syncthreads();
+    const uint32_t c0 = tid * BGZF_CHUNK;
+    uint32_t bits = 0, part = 0;
+    if (c0 < N) {
+        const uint32_t len = min(BGZF_CHUNK, N - c0);
+        uint32_t crc;
+        const ChunkTokens t = chunk_tokens<true>(in_lds, tid, len, crc_tab, &crc);
+        CountSink s{0};
+        walk_tokens(t, reinterpret_cast<const uint8_t*>(in_lds + tid * (BGZF_CHUNK_WORDS + 1u)), tab, s);
+        bits = s.bits;
+        // CRC-32 of the block: combine the chunk CRCs, crc(A||B) = crc(A) * x^(8|B|) + crc(B)
+        const uint32_t after = N - (c0 + len); // bytes behind this chunk
+        const uint32_t q = after / BGZF_CHUNK, r = after - q * BGZF_CHUNK;
+        uint32_t sh = p.tables->crc_shift_chunk[q];
+        if (r) sh = crc_mulmod(sh, p.tables->crc_shift_byte[r]);
+        part = after ? crc_mulmod(sh, crc) : crc;
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) part ^= __shfl_xor(part, d, 64);
+    if ((tid & 63u) == 0) scratch[tid >> 6] = part;
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t block_crc = 0;
+        for (uint32_t w = 0; w < BGZF_WAVES; ++w) block_crc ^= scratch[w];
+        p.crcs[b] = block_crc;
+    }
+    p.thread_bits[(uint64_t)b * BGZF_THREADS + tid] = (uint16_t)bits; // <= 64 literals of <= 15 bits
+    uint32_t total;
+    block_exclusive_scan(bits, scratch, &total);
+    if (tid == 0) {
+        const uint32_t body_bits = p.tables->hdr_nbits + total + (p.tables->eob & 31u);
+        const uint32_t body = (body_bits + 7u) >> 3;
+        const uint32_t stored = N + 5u;
+        if (body > BGZF_OUT_LARGE || body >= stored) p.sizes[b] = (stored + BGZF_MEMBER_OVERHEAD) | 0x80000000u;
+        else p.sizes[b] = (body + BGZF_MEMBER_OVERHEAD) | (body > BGZF_OUT_SMALL ? 0x40000000u : 0u);
+    }
+}
+
+// exclusive scan of the member sizes: one workgroup, sequential over slices (n_blocks is a few 10^5)
+__global__ __launch_bounds__(1024) void bgzf_scan(const uint32_t* sizes, uint32_t n, uint64_t* offsets, uint32_t* large_list)
+{
+    __shared__ uint64_t part[1024];
+    __shared__ uint32_t lpart[1024];
+    const uint32_t per = (n + 1023u) / 1024u;
+    const uint32_t lo = min(n, threadIdx.x * per), hi = min(n, lo + per);
+    uint64_t s = 0;
+    uint32_t nl = 0;
+    for (uint32_t i = lo; i < hi; ++i) { s += sizes[i] & 0x3FFFFFFFu; nl += (sizes[i] >> 30) & 1u; }
+    part[threadIdx.x] = s;
+    lpart[threadIdx.x] = nl;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint64_t run = 0;
+        uint32_t lrun = 0;
+        for (uint32_t i = 0; i < 1024; ++i) {
+            const uint64_t t = part[i]; part[i] = run; run += t;
+            const uint32_t u = lpart[i]; lpart[i] = lrun; lrun += u;
+        }
+        offsets[n] = run;
+        large_list[0] = lrun;
+    }
+    __syncthreads();
+    uint64_t run = part[threadIdx.x];
+    uint32_t lrun = lpart[threadIdx.x];
+    for (uint32_t i = lo; i < hi; ++i) {
+        offsets[i] = run;
+        run += sizes[i] & 0x3FFFFFFFu;
+        if ((sizes[i] >> 30) & 1u) large_list[1u + lrun++] = i;
+    }
+}
+
+// OUT_BYTES = BGZF_OUT_SMALL: every member whose body fits 8 KB, and the stored ones (LDS < 80 KB: two
+// workgroups per CU).  OUT_BYTES = BGZF_OUT_LARGE: the rest.  Both are launched over all blocks; a
+// workgroup whose block belongs to the other kernel exits at once.
+template <uint32_t OUT_BYTES>
+__global__ __launch_bounds__(BGZF_THREADS, OUT_BYTES == BGZF_OUT_SMALL ? 8 : 4) void bgzf_encode(const BgzfParams p)
+{
+    __shared__ uint32_t in_lds[BGZF_LDS_IN_WORDS];
+    __shared__ uint32_t outbuf[OUT_BYTES / 4];
+    __shared__ uint32_t tab[512];
+    __shared__ uint32_t scratch[BGZF_WAVES];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t b = OUT_BYTES == BGZF_OUT_LARGE ? p.large_list[1u + blockIdx.x] : blockIdx.x;
     const uint32_t N = block_len(p, b);
     const uint8_t* blk = p.text + (uint64_t)b * BGZF_IN;
     uint8_t* dst = p.out + p.offsets[b];
-    const uint32_t size = p.sizes[b] & 0x7FFFFFFFu;
+    const uint32_t size = p.sizes[b] & 0x3FFFFFFFu;
     const bool stored = p.sizes[b] >> 31;
+    if (((p.sizes[b] >> 30) & 1u) != (OUT_BYTES == BGZF_OUT_LARGE ? 1u : 0u)) return; // the other kernel's block
 
     load_code_table(p, tab);
-    crc_tab[tid >> 8][tid & 255u] = p.tables->crc_table[tid >> 8][tid & 255u];
-    for (uint32_t i = tid; i < BGZF_LDS_OUT / 4; i += BGZF_THREADS) outbuf[i] = 0;
+    for (uint32_t i = tid; i < (size - BGZF_MEMBER_OVERHEAD + 3u) / 4u && i < OUT_BYTES / 4; i += BGZF_THREADS) outbuf[i] = 0;
     stage_block(blk, N, in_lds);
     __syncthreads();
 
@@ -331,14 +371,10 @@ __global__ __launch_bounds__(BGZF_THREADS) void bgzf_encode(const BgzfParams p)
     const uint32_t len = c0 < N ? min(BGZF_CHUNK, N - c0) : 0u;
     const uint8_t* chunk = reinterpret_cast<const uint8_t*>(in_lds + tid * (BGZF_CHUNK_WORDS + 1u));
     ChunkTokens t{0, 0, 0};
-    uint32_t bits = 0, crc = 0;
-    if (len) {
-        t = chunk_tokens<true>(in_lds, tid, len, crc_tab, &crc);
-        if (!stored) {
-            CountSink s{0};
-            walk_tokens(t, chunk, tab, s);
-            bits = s.bits;
-        }
+    uint32_t bits = 0;
+    if (len && !stored) {
+        t = chunk_tokens<false>(in_lds, tid, len, nullptr, nullptr);
+        bits = p.thread_bits[(uint64_t)b * BGZF_THREADS + tid]; // counted by bgzf_size
     }
     uint32_t total;
     const uint32_t prefix = block_exclusive_scan(bits, scratch, &total);
@@ -359,22 +395,8 @@ __global__ __launch_bounds__(BGZF_THREADS) void bgzf_encode(const BgzfParams p)
             e.flush();
         }
     }
-    // CRC-32 of the block: combine the chunk CRCs, crc(A||B) = crc(A) * x^(8|B|) + crc(B)
-    uint32_t part = 0;
-    if (len) {
-        const uint32_t after = N - (c0 + len); // bytes behind this chunk
-        const uint32_t q = after / BGZF_CHUNK, r = after - q * BGZF_CHUNK;
-        uint32_t sh = p.tables->crc_shift_chunk[q];
-        if (r) sh = crc_mulmod(sh, p.tables->crc_shift_byte[r]);
-        part = after ? crc_mulmod(sh, crc) : crc;
-    }
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) part ^= __shfl_xor(part, d, 64);
-    __syncthreads(); // scratch is free again, and outbuf is complete
-    if ((tid & 63u) == 0) scratch[tid >> 6] = part;
-    __syncthreads();
-    uint32_t block_crc = 0;
-    for (uint32_t w = 0; w < BGZF_WAVES; ++w) block_crc ^= scratch[w];
+    __syncthreads(); // outbuf is complete
+    const uint32_t block_crc = p.crcs[b];
 
     // gzip member header (RFC 1952) with the BGZF extra field: BSIZE = member size - 1
     if (tid < 18) {

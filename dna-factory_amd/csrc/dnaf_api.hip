@@ -83,6 +83,9 @@ struct dnaf_ctx {
     bool have_tables = false;
     uint32_t* d_hist = nullptr;
     uint32_t* d_sizes = nullptr;
+    uint16_t* d_thread_bits = nullptr;
+    uint32_t* d_crcs = nullptr;
+    uint32_t* d_large = nullptr;
     uint64_t* d_offsets = nullptr;
     uint64_t blocks_cap = 0;
     uint8_t* d_bgzf = nullptr;
@@ -191,6 +194,9 @@ int dnaf_destroy(dnaf_ctx* c)
     dev_free(c->d_tables);
     dev_free(c->d_hist);
     dev_free(c->d_sizes);
+    dev_free(c->d_thread_bits);
+    dev_free(c->d_crcs);
+    dev_free(c->d_large);
     dev_free(c->d_offsets);
     dev_free(c->d_bgzf);
     for (hipEvent_t e : c->zev) if (e) (void)hipEventDestroy(e);
@@ -785,9 +791,15 @@ int dnaf_bgzf_compress(dnaf_ctx* c, uint32_t flags, uint64_t* n_bytes)
     if (nb > c->blocks_cap) {
         HIP_TRY(c, hipStreamSynchronize(c->stream));
         dev_free(c->d_sizes);
+        dev_free(c->d_thread_bits);
+        dev_free(c->d_crcs);
+        dev_free(c->d_large);
         dev_free(c->d_offsets);
         c->blocks_cap = 0;
+        HIP_TRY(c, hipMalloc((void**)&c->d_crcs, (uint64_t)nb * sizeof(uint32_t)));
+        HIP_TRY(c, hipMalloc((void**)&c->d_large, ((uint64_t)nb + 1) * sizeof(uint32_t)));
         HIP_TRY(c, hipMalloc((void**)&c->d_sizes, (uint64_t)nb * sizeof(uint32_t)));
+        HIP_TRY(c, hipMalloc((void**)&c->d_thread_bits, (uint64_t)nb * dnaf::BGZF_THREADS * sizeof(uint16_t)));
         HIP_TRY(c, hipMalloc((void**)&c->d_offsets, ((uint64_t)nb + 1) * sizeof(uint64_t)));
         c->blocks_cap = nb;
     }
@@ -799,6 +811,9 @@ int dnaf_bgzf_compress(dnaf_ctx* c, uint32_t flags, uint64_t* n_bytes)
     p.tables = c->d_tables;
     p.hist = c->d_hist;
     p.sizes = c->d_sizes;
+    p.thread_bits = c->d_thread_bits;
+    p.crcs = c->d_crcs;
+    p.large_list = c->d_large;
     p.offsets = c->d_offsets;
     p.out = nullptr;
     float ms_total = 0.f, ms = 0.f;
@@ -826,10 +841,12 @@ int dnaf_bgzf_compress(dnaf_ctx* c, uint32_t flags, uint64_t* n_bytes)
     HIP_TRY(c, hipEventRecord(c->zev[0], c->stream));
     hipLaunchKernelGGL(dnaf::bgzf_size, dim3(nb), dim3(dnaf::BGZF_THREADS), 0, c->stream, p);
     HIP_TRY(c, hipGetLastError());
-    hipLaunchKernelGGL(dnaf::bgzf_scan, dim3(1), dim3(1024), 0, c->stream, (const uint32_t*)c->d_sizes, nb, c->d_offsets);
+    uint32_t n_large = 0;
+    hipLaunchKernelGGL(dnaf::bgzf_scan, dim3(1), dim3(1024), 0, c->stream, (const uint32_t*)c->d_sizes, nb, c->d_offsets, c->d_large);
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipEventRecord(c->zev[1], c->stream));
     HIP_TRY(c, hipMemcpyAsync(&total, c->d_offsets + nb, sizeof total, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(&n_large, c->d_large, sizeof n_large, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     HIP_TRY(c, hipEventElapsedTime(&ms, c->zev[0], c->zev[1]));
     ms_total += ms;
@@ -843,8 +860,12 @@ int dnaf_bgzf_compress(dnaf_ctx* c, uint32_t flags, uint64_t* n_bytes)
     // 4. encode every member at its offset
     p.out = c->d_bgzf;
     HIP_TRY(c, hipEventRecord(c->zev[0], c->stream));
-    hipLaunchKernelGGL(dnaf::bgzf_encode, dim3(nb), dim3(dnaf::BGZF_THREADS), 0, c->stream, p);
+    hipLaunchKernelGGL((dnaf::bgzf_encode<dnaf::BGZF_OUT_SMALL>), dim3(nb), dim3(dnaf::BGZF_THREADS), 0, c->stream, p);
     HIP_TRY(c, hipGetLastError());
+    if (n_large) {
+        hipLaunchKernelGGL((dnaf::bgzf_encode<dnaf::BGZF_OUT_LARGE>), dim3(n_large), dim3(dnaf::BGZF_THREADS), 0, c->stream, p);
+        HIP_TRY(c, hipGetLastError());
+    }
     HIP_TRY(c, hipEventRecord(c->zev[1], c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     HIP_TRY(c, hipEventElapsedTime(&ms, c->zev[0], c->zev[1]));

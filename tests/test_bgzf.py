@@ -146,7 +146,7 @@ def _members(blob):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n_rows,S", [(1, 1), (3, 0), (40, 333), (900, 2000), (64, 20000), (16, 64512 // 4)])
+@pytest.mark.parametrize("n_rows,S", [(1, 1), (3, 0), (40, 333), (900, 2000), (64, 20000), (16, 61440 // 4)])
 def test_gpu_bgzf_inflates_to_the_text(capi, n_rows, S):
     from dna_factory_amd.rowgen import RowGenerator
 
@@ -163,7 +163,7 @@ def test_gpu_bgzf_inflates_to_the_text(capi, n_rows, S):
     assert gzip.decompress(raw) == text.tobytes()  # checks every member's CRC-32 and ISIZE too
     assert gzip.decompress(blob2.tobytes()) == text.tobytes()
     members = _members(raw)
-    assert len(members) == max(1, -(-len(text) // 64512)) and max(len(m) for m in members) <= 65536
+    assert len(members) == max(1, -(-len(text) // 61440)) and max(len(m) for m in members) <= 65536
     if S >= 2000:
         assert len(raw) * 4 < len(text)  # even on this worst-case mix (MAF uniform to 0.5, 30 % sex chromosomes)
     # a BGZF reader sees a valid file once the EOF block is appended
@@ -195,5 +195,5 @@ def test_gpu_bgzf_stored_fallback_on_incompressible_text(capi):
         raw = g.ctx.read_bgzf(g.ctx.bgzf_compress()).tobytes()
     assert gzip.decompress(raw) == text
     members = _members(raw)
-    full = [m for m in members if len(m) == 64512 + 5 + 26]
+    full = [m for m in members if len(m) == 61440 + 5 + 26]
     assert len(full) >= 2 and all(m[18] == 1 for m in full)  # BFINAL=1, BTYPE=00
