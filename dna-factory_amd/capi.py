@@ -33,7 +33,7 @@ SYMBOLS = [
     "dnaf_sync", "dnaf_last_generate_ms", "dnaf_timing_begin", "dnaf_timing_end", "dnaf_read_text", "dnaf_read_packed", "dnaf_device_buffers",
     "dnaf_format_prefixes", "dnaf_bgzf_compress", "dnaf_read_bgzf", "dnaf_last_bgzf_ms",
     "dnaf_bgzf_tables_from_histogram", "dnaf_set_mt_state", "dnaf_mt_jump_host", "dnaf_mt_characteristic_polynomial",
-    "dnaf_fetch_bgzf", "dnaf_fetch_text", "dnaf_read_text_range",
+    "dnaf_fetch_bgzf", "dnaf_fetch_text", "dnaf_read_text_range", "dnaf_format_snps_json", "dnaf_parse_snps_json",
 ]
 
 
@@ -93,6 +93,8 @@ def _load():
         "dnaf_fetch_bgzf": (ci, [vp, vp, vp]),
         "dnaf_fetch_text": (ci, [vp, vp, vp]),
         "dnaf_read_text_range": (ci, [vp, u64, u64, vp]),
+        "dnaf_format_snps_json": (ci, [u64, vp, vp, u32, vp, vp, u32, vp, u32, vp, vp, vp, vp, vp, u64, vp]),
+        "dnaf_parse_snps_json": (ci, [vp, u64, u64, vp, vp, u32, vp, vp, u32, vp, vp, vp]),
         "dnaf_mt_jump_host": (ci, [vp, u64, vp]),
         "dnaf_mt_characteristic_polynomial": (ci, [vp, vp]),
     }
@@ -141,6 +143,62 @@ def format_prefixes(chrom, pos, snp_id, ref, alt):
     if rc != OK:
         raise DnafError(rc, "dnaf_format_prefixes")
     return blob[: int(off[n])], off
+
+
+def format_snps_json(snp_id, chrom, pos, ref, alt, n_alleles, cum):
+    """The text of snps.json.gz for these rows (one `str(SNPTuples)` per line, pop_factory.py:118-124) as bytes.
+    Returns None when a field would need JSON escaping (the caller then formats in Python)."""
+    n = len(snp_id)
+    chrom, ref, alt = np.ascontiguousarray(chrom), np.ascontiguousarray(ref), np.ascontiguousarray(alt)
+    for a in (chrom, ref, alt):
+        raw = a.view(np.uint8)
+        if raw.size and (np.any(raw == 0x22) or np.any(raw == 0x5C) or np.any((raw != 0) & (raw < 0x20)) or np.any(raw > 0x7E)):
+            return None
+    snp_id = np.ascontiguousarray(snp_id, dtype=np.int64)
+    pos = np.ascontiguousarray(pos, dtype=np.int64)
+    n_alleles = np.ascontiguousarray(n_alleles, dtype=np.uint8)
+    cum = np.ascontiguousarray(cum, dtype=np.float64)
+    uniq, inv = np.unique(cum, return_inverse=True)
+    if np.any(~np.isfinite(uniq)):
+        return None
+    strs = [repr(float(u)).encode() for u in uniq]  # json.dumps(float) is float.__repr__
+    num_off = np.zeros(len(strs) + 1, dtype=np.uint64)
+    num_off[1:] = np.cumsum([len(x) for x in strs])
+    num_blob = np.frombuffer(b"".join(strs) or b"\0", dtype=np.uint8)
+    cum_idx = np.ascontiguousarray(inv.reshape(cum.shape), dtype=np.int32)
+    nb = ctypes.c_uint64(0)
+    args = (n, ptr(snp_id), ptr(chrom), chrom.dtype.itemsize, ptr(pos), ptr(ref), ref.dtype.itemsize, ptr(alt),
+            alt.dtype.itemsize, ptr(n_alleles), ptr(cum_idx), ptr(num_blob), ptr(num_off))
+    rc = lib.dnaf_format_snps_json(*args, None, 0, ctypes.byref(nb))
+    if rc != OK:
+        raise DnafError(rc, "dnaf_format_snps_json (sizing)")
+    out = np.empty(max(nb.value, 1), dtype=np.uint8)
+    rc = lib.dnaf_format_snps_json(*args, ptr(out), nb.value, ctypes.byref(nb))
+    if rc != OK:
+        raise DnafError(rc, "dnaf_format_snps_json")
+    return out[: nb.value]
+
+
+def parse_snps_json(text, chrom_w=8, allele_w=16):
+    """Columns of a snps.json text (bytes): (id, chrom S, pos, alleles S[n][4], cum f64[n][4], n_alleles) or None when
+    a line is outside the fast path's format."""
+    buf = np.frombuffer(text, dtype=np.uint8)
+    max_rows = int(np.count_nonzero(buf == 0x0A)) + 1
+    sid = np.zeros(max_rows, dtype=np.int64)
+    pos = np.zeros(max_rows, dtype=np.int64)
+    chrom = np.zeros(max_rows, dtype="S%d" % chrom_w)
+    alleles = np.zeros((max_rows, 4), dtype="S%d" % allele_w)
+    cum = np.ones((max_rows, 4), dtype=np.float64)
+    na = np.zeros(max_rows, dtype=np.uint8)
+    n = ctypes.c_uint64(0)
+    rc = lib.dnaf_parse_snps_json(ptr(buf) if len(buf) else None, len(buf), max_rows, ptr(sid), ptr(chrom), chrom_w, ptr(pos),
+                                  ptr(alleles), allele_w, ptr(cum), ptr(na), ctypes.byref(n)) if len(buf) else OK
+    if rc == ERR_UNSUPPORTED:
+        return None
+    if rc != OK:
+        raise DnafError(rc, "dnaf_parse_snps_json")
+    k = n.value
+    return sid[:k], chrom[:k], pos[:k], alleles[:k], cum[:k], na[:k]
 
 
 class Context:

@@ -1025,3 +1025,130 @@ int dnaf_mt_characteristic_polynomial(uint64_t* words312, int* degree)
 }
 
 } // extern "C"
+
+// ---- host helper: snps.json.gz lines, str(SNPTuples) of pop_factory.py:118-124 ----
+extern "C" {
+
+// One JSON object per row, newline-terminated:
+//   {"id": <id>, "chromosome": "<chrom>", "position": <pos>, "tuples": {"<ref>": <cum0>, "<alt1>": <cum1>, ...}}
+// ref / alt are the fixed-width fields of dnaf_format_prefixes (alt comma-joined); the cumulative
+// frequencies are given as indices into a table of already formatted numbers (repr(float), done by the
+// caller once per distinct value): num_off[k] .. num_off[k+1] in num_blob.  Pass out == NULL to size.
+int dnaf_format_snps_json(uint64_t n, const int64_t* id, const char* chrom, uint32_t chrom_w, const int64_t* pos,
+                          const char* ref, uint32_t ref_w, const char* alt, uint32_t alt_w, const uint8_t* n_alleles,
+                          const int32_t* cum_idx /* [n][4] */, const char* num_blob, const uint64_t* num_off,
+                          uint8_t* out, uint64_t out_cap, uint64_t* n_bytes)
+{
+    if (!n_bytes || (n && (!id || !chrom || !pos || !ref || !alt || !n_alleles || !cum_idx || !num_blob || !num_off))) return DNAF_ERR_BAD_ARG;
+    uint64_t o = 0;
+    uint8_t scratch[48];
+    auto put = [&](const void* p, size_t len) {
+        if (out && o + len <= out_cap) memcpy(out + o, p, len);
+        o += len;
+    };
+    auto put_s = [&](const char* s) { put(s, strlen(s)); };
+    for (uint64_t j = 0; j < n; ++j) {
+        const char *c = chrom + j * chrom_w, *r = ref + j * ref_w, *a = alt + j * alt_w;
+        const size_t cl = field_len(c, chrom_w), rl = field_len(r, ref_w), al = field_len(a, alt_w);
+        put_s("{\"id\": ");
+        put(scratch, put_i64(scratch, id[j]));
+        put_s(", \"chromosome\": \"");
+        put(c, cl);
+        put_s("\", \"position\": ");
+        put(scratch, put_i64(scratch, pos[j]));
+        put_s(", \"tuples\": {\"");
+        put(r, rl);
+        put_s("\": ");
+        const int32_t k0 = cum_idx[j * 4];
+        put(num_blob + num_off[k0], num_off[k0 + 1] - num_off[k0]);
+        size_t p0 = 0;
+        for (uint32_t k = 1; k < n_alleles[j]; ++k) {
+            size_t p1 = p0;
+            while (p1 < al && a[p1] != ',') ++p1;
+            put_s(", \"");
+            put(a + p0, p1 - p0);
+            put_s("\": ");
+            const int32_t kk = cum_idx[j * 4 + k];
+            put(num_blob + num_off[kk], num_off[kk + 1] - num_off[kk]);
+            p0 = p1 < al ? p1 + 1 : p1;
+        }
+        put_s("}}\n");
+    }
+    *n_bytes = o;
+    if (out && o > out_cap) return DNAF_ERR_BAD_ARG;
+    return DNAF_OK;
+}
+
+} // extern "C"
+
+// ---- host helper: parse snps.json.gz text (SNPTuples.from_json, pop_factory.py:126-133, :264-272) ----
+extern "C" {
+
+// Parses lines of the form written by str(SNPTuples):
+//   {"id": 5, "chromosome": "X", "position": 10, "tuples": {"A": 0.1, "T": 1.0}}
+// (key order as shown; the key order of "tuples" is the allele order).  alleles: [max_rows][4] fields of
+// allele_w bytes, NUL padded.  Returns DNAF_ERR_UNSUPPORTED on any line it does not understand (escapes,
+// other key order, more than 4 alleles, over-long fields): the caller then falls back to a JSON parser.
+int dnaf_parse_snps_json(const char* text, uint64_t n_bytes, uint64_t max_rows, int64_t* id, char* chrom, uint32_t chrom_w,
+                         int64_t* pos, char* alleles, uint32_t allele_w, double* cum, uint8_t* n_alleles, uint64_t* n_rows)
+{
+    if (!text || !id || !chrom || !pos || !alleles || !cum || !n_alleles || !n_rows) return DNAF_ERR_BAD_ARG;
+    const char *p = text, *end = text + n_bytes;
+    uint64_t j = 0;
+    auto lit = [&](const char* s) {
+        const size_t n = strlen(s);
+        if ((size_t)(end - p) < n || memcmp(p, s, n) != 0) return false;
+        p += n;
+        return true;
+    };
+    auto integer = [&](int64_t* v) {
+        bool neg = false;
+        if (p < end && *p == '-') { neg = true; ++p; }
+        if (p >= end || *p < '0' || *p > '9') return false;
+        uint64_t u = 0;
+        while (p < end && *p >= '0' && *p <= '9') u = u * 10 + (uint64_t)(*p++ - '0');
+        *v = neg ? -(int64_t)u : (int64_t)u;
+        return true;
+    };
+    auto str = [&](char* dst, uint32_t w) { // after the opening quote; stops at the closing quote
+        uint32_t k = 0;
+        while (p < end && *p != '"') {
+            if (*p == '\\' || (unsigned char)*p < 0x20 || k >= w) return false;
+            dst[k++] = *p++;
+        }
+        if (p >= end) return false;
+        ++p;
+        return true;
+    };
+    while (p < end) {
+        if (*p == '\n') { ++p; continue; }
+        if (j >= max_rows) return DNAF_ERR_BAD_ARG;
+        memset(chrom + j * chrom_w, 0, chrom_w);
+        memset(alleles + j * 4 * allele_w, 0, 4 * (size_t)allele_w);
+        if (!lit("{\"id\": ") || !integer(&id[j]) || !lit(", \"chromosome\": \"") || !str(chrom + j * chrom_w, chrom_w) ||
+            !lit(", \"position\": ") || !integer(&pos[j]))
+            return DNAF_ERR_UNSUPPORTED;
+        uint32_t na = 0;
+        if (lit(", \"tuples\": {")) {
+            while (true) {
+                if (na >= 4 || !lit("\"") || !str(alleles + (j * 4 + na) * allele_w, allele_w) || !lit(": ")) return DNAF_ERR_UNSUPPORTED;
+                char* stop = nullptr;
+                cum[j * 4 + na] = strtod(p, &stop);
+                if (stop == p || stop > end) return DNAF_ERR_UNSUPPORTED;
+                p = stop;
+                ++na;
+                if (lit(", ")) continue;
+                if (lit("}")) break;
+                return DNAF_ERR_UNSUPPORTED;
+            }
+        }
+        if (!lit("}")) return DNAF_ERR_UNSUPPORTED;
+        if (p < end && *p != '\n') return DNAF_ERR_UNSUPPORTED;
+        n_alleles[j] = (uint8_t)na;
+        ++j;
+    }
+    *n_rows = j;
+    return DNAF_OK;
+}
+
+} // extern "C"

@@ -25,6 +25,55 @@ from .tables import SampleTable, SnpTable
 # ---------------------------------------------------------------------------------------------------------
 
 
+def _replay_random_choice3(count):
+    """The indices `count` successive `random.choice(<3-element list>)` calls return, leaving Python's `random`
+    exactly where those calls would leave it -- without a Python-level loop.
+
+    CPython: choice(seq) = seq[_randbelow(3)], and _randbelow(3) draws getrandbits(2) = next MT19937 word >> 30
+    until the value is below 3.  The words come from numpy's RandomState loaded with `random`'s own state (both wrap
+    the same generator), so the stream and the final state are the interpreter's.  A prefix is cross-checked against
+    real `random.choice` calls; on any disagreement (another interpreter's `random`) the plain loop is used."""
+    if count == 0:
+        return np.zeros(0, dtype=np.int64)
+    state = random.getstate()
+
+    def plain():
+        return np.fromiter((random.choice((0, 1, 2)) for _ in range(count)), dtype=np.int64, count=count)
+
+    if state[0] != 3 or len(state[1]) != 625:
+        return plain()
+    key = np.array(state[1][:624], dtype=np.uint32)
+    rs = numpy.random.RandomState()
+    rs.set_state(("MT19937", key, int(state[1][624])))
+    picks, consumed = [], 0
+    need = count
+    while need > 0:
+        words = rs.randint(0, 2**32, size=need + need // 2 + 64, dtype=np.uint32)
+        r = (words >> np.uint32(30)).astype(np.int64)
+        ok = np.flatnonzero(r < 3)
+        if len(ok) >= need:
+            ok = ok[:need]
+            picks.append(r[ok])
+            consumed += int(ok[-1]) + 1
+            need = 0
+        else:
+            picks.append(r[ok])
+            consumed += len(words)
+            need -= len(ok)
+    picks = np.concatenate(picks)
+    # cross-check a prefix against the interpreter, then put `random` where the calls would have left it
+    probe = min(count, 512)
+    real = [random.choice((0, 1, 2)) for _ in range(probe)]
+    random.setstate(state)
+    if real != [int(x) for x in picks[:probe]]:
+        return plain()
+    rs.set_state(("MT19937", key, int(state[1][624])))
+    rs.randint(0, 2**32, size=consumed, dtype=np.uint32)
+    end = rs.get_state()
+    random.setstate((3, tuple(int(x) for x in end[1]) + (int(end[2]),), state[2]))
+    return picks
+
+
 def generate_snp_table(size, min_maf=0.005):
     """The synthetic SNP list of SnpFactory.random_snp_tuples (pop_factory.py:172-193), sorted like
     pop_factory.py:245, as an SnpTable.  Consumes the global numpy / `random` streams exactly like the reference:
@@ -40,7 +89,8 @@ def generate_snp_table(size, min_maf=0.005):
     position_randoms = numpy.random.random(size)
     ref_idx = numpy.random.choice(4, size=size)  # same draws as choice(["A","T","C","G"], size)
     others = [[n for n in range(4) if n != r] for r in range(4)]  # remaining_nt after .remove(ref), in list order
-    alt_idx = np.fromiter((random.choice(others[r]) for r in ref_idx), dtype=np.int64, count=size)
+    pick = _replay_random_choice3(size)  # one random.choice(remaining_nt) per SNP, pop_factory.py:190
+    alt_idx = np.asarray(others, dtype=np.int64)[ref_idx, pick]
     max_pos = np.array([genome.CHROMOSOME_MAX_POSITION[c] for c in genome.CHROMOSOME_LIST], dtype=np.int64)
     position = (position_randoms * max_pos[chrom_idx]).astype(np.int64)  # int(rand * max), pop_factory.py:186
     names = np.array([c.encode() for c in genome.CHROMOSOME_LIST], dtype="S2")
@@ -66,34 +116,79 @@ def _float_repr_column(values):
     return reprs[inv]
 
 
-def write_snps_file(tb, path):
-    """snps.json.gz: one `str(SNPTuples)` per line (pop_factory.py:118-124, :258-262), gzip level 5."""
+def _snps_json_lines_python(tb, b, e):
+    lines = []
+    ref = tb.ref[b:e].astype("U")
+    chrom = tb.chrom[b:e].astype("U")
+    alts = [a.split(",") for a in tb.alt[b:e].astype("U")]
+    for j in range(e - b):
+        na = int(tb.n_alleles[b + j])
+        tuples = {ref[j]: float(tb.cum[b + j, 0])}
+        for k in range(1, na):
+            tuples[alts[j][k - 1]] = float(tb.cum[b + j, k])
+        lines.append(json.dumps({"id": int(tb.snp_id[b + j]), "chromosome": chrom[j],
+                                 "position": int(tb.position[b + j]), "tuples": tuples}))
+    return ("\n".join(lines) + "\n").encode() if lines else b""
+
+
+def _gzip_member(data, level):
+    return gzip.compress(data, compresslevel=level, mtime=0)
+
+
+def write_snps_file(tb, path, threads=8):
+    """snps.json.gz: one `str(SNPTuples)` per line (pop_factory.py:118-124, :258-262), gzip level 5.  Lines are
+    formatted by the library's C helper in slabs and compressed as independent gzip members on a thread pool
+    (a multi-member file is what `gzip.open(...).read()` and the reference's load_snps_file read transparently)."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    from . import capi
+
     n = len(tb)
-    with gzip.open(path, "wt", compresslevel=5) as f:
-        step = 200000
-        for b in range(0, n, step):
+    step = 250000
+    with open(path, "wb") as f, ThreadPoolExecutor(max_workers=max(1, threads)) as pool:
+        pending = []
+        for b in range(0, max(n, 1), step):
             e = min(n, b + step)
-            lines = []
-            ref = tb.ref[b:e].astype("U")
-            chrom = tb.chrom[b:e].astype("U")
-            alts = [a.split(",") for a in tb.alt[b:e].astype("U")]
-            for j in range(e - b):
-                na = int(tb.n_alleles[b + j])
-                tuples = {ref[j]: float(tb.cum[b + j, 0])}
-                for k in range(1, na):
-                    tuples[alts[j][k - 1]] = float(tb.cum[b + j, k])
-                lines.append(json.dumps({"id": int(tb.snp_id[b + j]), "chromosome": chrom[j],
-                                         "position": int(tb.position[b + j]), "tuples": tuples}))
-            f.write("\n".join(lines) + "\n")
+            blob = capi.format_snps_json(tb.snp_id[b:e], tb.chrom[b:e], tb.position[b:e], tb.ref[b:e], tb.alt[b:e],
+                                         tb.n_alleles[b:e], tb.cum[b:e]) if e > b else np.zeros(0, np.uint8)
+            data = _snps_json_lines_python(tb, b, e) if blob is None else blob.tobytes()
+            pending.append(pool.submit(_gzip_member, data, 5))
+            while len(pending) > 2 * threads:
+                f.write(pending.pop(0).result())
+        for fut in pending:
+            f.write(fut.result())
 
 
 def load_snps_file(path):
-    """Read snps.json.gz (SNPTuples.from_json, pop_factory.py:126-133, :264-272): key order of "tuples" is allele order."""
+    """Read snps.json.gz (SNPTuples.from_json, pop_factory.py:126-133, :264-272): key order of "tuples" is allele
+    order.  Files in the layout dna-factory writes go through the library's C parser; anything else through json."""
+    from . import capi
+
+    with gzip.open(path, "rb") as f:
+        text = f.read()
+    cols = capi.parse_snps_json(text)
+    if cols is not None:
+        sid, chrom, pos, alleles, cum, na = cols
+        if len(sid) and (na.min() < 1):
+            cols = None  # a record without alleles: let from_snps report it
+    if cols is not None:
+        sid, chrom, pos, alleles, cum, na = cols
+        ref = alleles[:, 0]
+        alt = np.where(na == 1, alleles[:, 0], alleles[:, 1]).astype("S64")
+        for j in np.flatnonzero(na > 2):  # ",".join of the other alleles (alt_alleles(), pop_factory.py:111-116)
+            alt[j] = b",".join(alleles[j, 1: na[j]])
+        cum = cum.copy()
+        for k in range(4):
+            cum[na <= k, k] = 1.0
+        w = max([1] + [len(x) for x in alt[na > 2]]) if np.any(na > 2) else 1
+        w = max(w, int(np.max(np.char.str_len(alt))) if len(alt) else 1)
+        return SnpTable(sid, chrom, pos, ref, alt.astype("S%d" % w), na, cum)
     snps = []
-    with gzip.open(path, "rt") as f:
-        for line in f:
-            o = json.loads(line)
-            snps.append((o["id"], o["chromosome"], o["position"], list(o.get("tuples", {}).items())))
+    for line in text.decode().splitlines():
+        if not line:
+            continue
+        o = json.loads(line)
+        snps.append((o["id"], o["chromosome"], o["position"], list(o.get("tuples", {}).items())))
     return SnpTable.from_snps(snps)
 
 

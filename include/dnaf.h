@@ -166,6 +166,19 @@ int dnaf_fetch_text(dnaf_ctx* ctx, const void** host, uint64_t* n_bytes);
 int dnaf_last_bgzf_ms(dnaf_ctx* ctx, float* ms);
 /* Host-only helper: the encoder's code tables for a token histogram (256 literal counts, 256 counts
  * of match lengths 3..258, end-of-block count); out receives an opaque table blob. */
+/* Host helper: the lines of snps.json.gz, one str(SNPTuples) per row (pop_factory.py:118-124, :258-262).
+ * Numbers are passed as indices into a table of formatted values (repr(float) per distinct value). */
+int dnaf_format_snps_json(uint64_t n, const int64_t* id, const char* chrom, uint32_t chrom_w, const int64_t* pos,
+                          const char* ref, uint32_t ref_w, const char* alt, uint32_t alt_w, const uint8_t* n_alleles,
+                          const int32_t* cum_idx, const char* num_blob, const uint64_t* num_off, uint8_t* out,
+                          uint64_t out_cap, uint64_t* n_bytes);
+
+/* Host helper: the inverse, for files written by dna-factory or by this library (SNPTuples.from_json,
+ * pop_factory.py:126-133).  alleles: [max_rows][4] NUL-padded fields of allele_w bytes in "tuples" key order.
+ * DNAF_ERR_UNSUPPORTED = a line this fast path does not understand (use a JSON parser instead). */
+int dnaf_parse_snps_json(const char* text, uint64_t n_bytes, uint64_t max_rows, int64_t* id, char* chrom, uint32_t chrom_w,
+                         int64_t* pos, char* alleles, uint32_t allele_w, double* cum, uint8_t* n_alleles, uint64_t* n_rows);
+
 /* Host-only helpers of the MT19937 mode (tests): the window of 624 untempered words J >= 1 words after
  * base[624]; the characteristic polynomial of the generator (312 coefficient words, degree). */
 int dnaf_mt_jump_host(const uint32_t* base, uint64_t J, uint32_t* window);

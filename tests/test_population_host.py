@@ -105,3 +105,44 @@ def test_bad_yaml_bounds_raise_like_the_reference(pop, tmp_path):
     cfg.write_text("g:\n  mutation_weights: [1]\n  population_weight: 1\n  max_minor_allele_freq: 0.0001\n")
     with pytest.raises(Exception, match="No SNPs in list to choose from"):
         pop.pick_deleterious(tb, str(cfg))
+
+
+def test_fast_snps_json_helpers_match_python_json(pop, tmp_path):
+    """The library's C formatter / parser for snps.json.gz against json.dumps / json.loads, incl. multi-allelic
+    rows, a single-tuple row and multi-character alleles; other layouts fall back to the JSON parser."""
+    from dna_factory_amd import capi
+    from dna_factory_amd.tables import SnpTable
+
+    tb = SnpTable.from_snps([(5, "X", 10, [("A", 0.1), ("T", 0.75), ("G", 1.0)]), (6, "MT", 0, [("C", 1.0)]),
+                             (7, "2", 99, [("G", 0.25), ("A", 0.5), ("C", 0.875), ("T", 1.0)]),
+                             (8, "1", 3, [("AT", 1 - 0.005 * 7), ("G", 1.0)]), (2**40, "22", 248946339, [("T", 0.505), ("C", 1.0)])])
+    blob = capi.format_snps_json(tb.snp_id, tb.chrom, tb.position, tb.ref, tb.alt, tb.n_alleles, tb.cum)
+    assert blob.tobytes() == pop._snps_json_lines_python(tb, 0, len(tb))
+    path = tmp_path / "s.json.gz"
+    pop.write_snps_file(tb, path, threads=2)
+    back = pop.load_snps_file(path)
+    for col in ("snp_id", "chrom", "position", "ref", "alt", "n_alleles"):
+        assert np.array_equal(getattr(back, col), getattr(tb, col)), col
+    assert np.array_equal(back.cum, tb.cum)
+    # a quote in an allele needs JSON escaping: the C formatter declines, the writer falls back, the reader too
+    odd = SnpTable.from_snps([(1, "1", 5, [('A"', 0.5), ("C", 1.0)])])
+    assert capi.format_snps_json(odd.snp_id, odd.chrom, odd.position, odd.ref, odd.alt, odd.n_alleles, odd.cum) is None
+    pop.write_snps_file(odd, path)
+    assert pop.load_snps_file(path).ref[0] == b'A"'
+    with gzip.open(path, "wt") as f:  # compact separators: not the fast path's layout
+        f.write('{"id":1,"chromosome":"1","position":5,"tuples":{"A":0.5,"C":1.0}}\n')
+    assert capi.parse_snps_json(gzip.open(path, "rb").read()) is None
+    assert pop.load_snps_file(path).cum[0, 0] == 0.5
+
+
+def test_random_choice_replay_leaves_python_random_in_step(pop):
+    """generate_snp_table draws its per-SNP alternative allele without a Python loop; the values and the state of
+    `random` afterwards are those of the loop it replaces (random.choice per SNP, pop_factory.py:190)."""
+    for count in (1, 2, 511, 512, 513, 5000):
+        random.seed(1234 + count)
+        want = [random.choice((0, 1, 2)) for _ in range(count)]
+        after = random.getstate()
+        random.seed(1234 + count)
+        got = pop._replay_random_choice3(count)
+        assert [int(x) for x in got] == want
+        assert random.getstate() == after
