@@ -34,6 +34,7 @@ SYMBOLS = [
     "dnaf_format_prefixes", "dnaf_bgzf_compress", "dnaf_read_bgzf", "dnaf_last_bgzf_ms",
     "dnaf_bgzf_tables_from_histogram", "dnaf_set_mt_state", "dnaf_mt_jump_host", "dnaf_mt_characteristic_polynomial",
     "dnaf_fetch_bgzf", "dnaf_fetch_text", "dnaf_read_text_range", "dnaf_format_snps_json", "dnaf_parse_snps_json",
+    "dnaf_allele_counts",
 ]
 
 
@@ -93,6 +94,7 @@ def _load():
         "dnaf_fetch_bgzf": (ci, [vp, vp, vp]),
         "dnaf_fetch_text": (ci, [vp, vp, vp]),
         "dnaf_read_text_range": (ci, [vp, u64, u64, vp]),
+        "dnaf_allele_counts": (ci, [vp, vp, u64]),
         "dnaf_format_snps_json": (ci, [u64, vp, vp, u32, vp, vp, u32, vp, u32, vp, vp, vp, vp, vp, u64, vp]),
         "dnaf_parse_snps_json": (ci, [vp, u64, u64, vp, vp, u32, vp, vp, u32, vp, vp, vp]),
         "dnaf_mt_jump_host": (ci, [vp, u64, vp]),
@@ -309,6 +311,12 @@ class Context:
         got = ctypes.c_uint64(0)
         self._check(lib.dnaf_read_text(self._h, ptr(buf), n_bytes, ctypes.byref(got)))
         return buf[: got.value]
+
+    def allele_counts(self, n_rows):
+        """(control alt-allele count, case alt-allele count) per row of the last generated packed matrix: u32[n][2]."""
+        out = np.zeros((n_rows, 2), dtype=np.uint32)
+        self._check(lib.dnaf_allele_counts(self._h, ptr(out.reshape(-1)) if n_rows else None, n_rows))
+        return out
 
     def read_text_range(self, byte_begin, n_bytes):
         buf = np.empty(max(n_bytes, 1), dtype=np.uint8)

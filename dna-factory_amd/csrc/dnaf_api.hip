@@ -37,6 +37,9 @@ struct dnaf_ctx {
     uint32_t S = 0, G = 0, W = 0, n_male = 0;
     uint64_t x_row_bytes = 0; // cells of an X row
     uint8_t* d_male_nib = nullptr;
+    uint32_t* d_ctrl2 = nullptr; // [W] 2-bit-domain mask of the control samples
+    uint32_t* d_counts = nullptr;
+    uint64_t counts_cap = 0;
     uint32_t* d_xoff = nullptr;
     std::vector<uint8_t> h_flags;
 
@@ -179,6 +182,7 @@ int dnaf_destroy(dnaf_ctx* c)
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     dev_free(c->d_male_nib);
+    dev_free(c->d_ctrl2);
     dev_free(c->d_xoff);
     dev_free(c->d_forced);
     dev_free(c->d_recs);
@@ -186,6 +190,7 @@ int dnaf_destroy(dnaf_ctx* c)
     dev_free(c->d_text);
     dev_free(c->d_packed);
     if (c->h_pinned) (void)hipHostFree(c->h_pinned);
+    dev_free(c->d_counts);
     dev_free(c->d_thr53);
     dev_free(c->d_mt_base);
     dev_free(c->d_mt_states);
@@ -220,6 +225,7 @@ int dnaf_set_samples(dnaf_ctx* c, const uint8_t* flags, uint64_t n_samples)
     c->slot_of.clear();
     dev_free(c->d_forced);
     dev_free(c->d_male_nib);
+    dev_free(c->d_ctrl2);
     dev_free(c->d_xoff);
     c->S = (uint32_t)n_samples;
     c->G = (c->S + 3u) / 4u;
@@ -239,6 +245,13 @@ int dnaf_set_samples(dnaf_ctx* c, const uint8_t* flags, uint64_t n_samples)
     xoff[c->G] = (uint32_t)off;
     c->n_male = n_male;
     c->x_row_bytes = off;
+    {
+        std::vector<uint32_t> ctrl2(c->W ? c->W : 1, 0);
+        for (uint32_t i = 0; i < c->S; ++i)
+            if (flags[i] & DNAF_SAMPLE_CONTROL) ctrl2[i >> 4] |= 3u << (2u * (i & 15u));
+        HIP_TRY(c, hipMalloc((void**)&c->d_ctrl2, ctrl2.size() * sizeof(uint32_t)));
+        HIP_TRY(c, hipMemcpy(c->d_ctrl2, ctrl2.data(), ctrl2.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    }
     HIP_TRY(c, hipMalloc((void**)&c->d_male_nib, nib.size()));
     HIP_TRY(c, hipMalloc((void**)&c->d_xoff, xoff.size() * sizeof(uint32_t)));
     HIP_TRY(c, hipMemcpy(c->d_male_nib, nib.data(), nib.size(), hipMemcpyHostToDevice));
@@ -726,6 +739,31 @@ int dnaf_read_text(dnaf_ctx* c, void* dst, uint64_t dst_cap, uint64_t* n_bytes)
     if (n && !dst) return fail(c, DNAF_ERR_BAD_ARG, "dnaf_read_text: dst is NULL");
     HIP_TRY(c, hipSetDevice(c->device));
     if (n) HIP_TRY(c, hipMemcpyAsync(dst, c->d_text, n, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return DNAF_OK;
+}
+
+// Per-row alternative-allele counts of the last generated packed matrix: counts[2*j] among the control
+// samples, counts[2*j+1] among the cases (set bits of the 2-bit codes; one wave per row).
+int dnaf_allele_counts(dnaf_ctx* c, uint32_t* counts, uint64_t cap_rows)
+{
+    if (!c) return DNAF_ERR_BAD_ARG;
+    if (!c->have_output || !(c->last_what & DNAF_OUT_PACKED)) return fail(c, DNAF_ERR_STATE, "dnaf_allele_counts: no packed matrix was generated");
+    const uint64_t n = c->last_rows;
+    if (n > cap_rows || (n && !counts)) return fail(c, DNAF_ERR_BAD_ARG, "dnaf_allele_counts: need room for %llu rows", (unsigned long long)n);
+    if (n == 0) return DNAF_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (n > c->counts_cap) {
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        dev_free(c->d_counts);
+        c->counts_cap = 0;
+        HIP_TRY(c, hipMalloc((void**)&c->d_counts, n * 2 * sizeof(uint32_t)));
+        c->counts_cap = n;
+    }
+    hipLaunchKernelGGL(dnaf::allele_count_kernel, dim3((uint32_t)((n + 3) / 4)), dim3(256), 0, c->stream,
+                       (const uint32_t*)c->d_packed, (const uint32_t*)c->d_ctrl2, c->W, n, c->d_counts);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipMemcpyAsync(counts, c->d_counts, n * 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return DNAF_OK;
 }

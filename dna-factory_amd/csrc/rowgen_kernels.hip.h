@@ -351,4 +351,31 @@ __global__ __launch_bounds__(256) void rowgen_kernel(const GenParams p)
     else row_segment<TEXT, PACKED, false>(c, rec.cls, g_begin, g_end, g_stop, lane);
 }
 
+// Case / control allele counts from the packed matrix (the check behind BASELINE config 5: per-SNP
+// alternative-allele frequency of cases vs controls).  One wave per row: popcounts of the row's words
+// split by the control mask (both bits of a control sample's code set in ctrl2), wave-reduced.
+__global__ __launch_bounds__(256) void allele_count_kernel(const uint32_t* packed, const uint32_t* ctrl2, uint32_t W,
+                                                           uint64_t n_rows, uint32_t* counts)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t row = (uint64_t)blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (row >= n_rows) return;
+    const uint32_t* p = packed + row * W;
+    uint32_t nc = 0, nk = 0;
+    for (uint32_t w = lane; w < W; w += 64u) {
+        const uint32_t v = p[w], m = ctrl2[w];
+        nc += (uint32_t)__builtin_popcount(v & m);
+        nk += (uint32_t)__builtin_popcount(v & ~m);
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        nc += __shfl_xor(nc, d, 64);
+        nk += __shfl_xor(nk, d, 64);
+    }
+    if (lane == 0) {
+        counts[2 * row] = nc;
+        counts[2 * row + 1] = nk;
+    }
+}
+
 } // namespace dnaf

@@ -142,6 +142,10 @@ int dnaf_timing_end(dnaf_ctx* ctx, double* total_ms, uint64_t* n_recorded, uint6
  * text: exactly dnaf_text_bytes() bytes; packed: n_rows*ceil(S/16) u32. */
 int dnaf_read_text(dnaf_ctx* ctx, void* dst, uint64_t dst_cap, uint64_t* n_bytes);
 int dnaf_read_packed(dnaf_ctx* ctx, uint32_t* dst, uint64_t dst_cap_words, uint64_t* n_words);
+/* Per-row alternative-allele counts of the last generated packed matrix, computed on the GPU:
+ * counts[2*j] = alternative alleles among the control samples of row j, counts[2*j+1] among the cases
+ * (the case/control frequency check of BASELINE config 5).  Synchronises. */
+int dnaf_allele_counts(dnaf_ctx* ctx, uint32_t* counts, uint64_t cap_rows);
 /* Bytes [byte_begin, byte_begin + n_bytes) of the last generated text (consumers that stream a tile out in pieces). */
 int dnaf_read_text_range(dnaf_ctx* ctx, uint64_t byte_begin, uint64_t n_bytes, void* dst);
 

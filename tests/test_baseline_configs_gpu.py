@@ -115,3 +115,67 @@ def test_config5_case_control_allele_frequency_skew(mods, tmp_path):
         alt = bits[j, :, 0] + bits[j, :, 1]
         sd = np.sqrt(2 * maf[j] * (1 - maf[j]) / (2 * n_ctrl))
         assert abs(alt[:n_ctrl].mean() / 2 - alt[n_ctrl:].mean() / 2) < 6 * sd + 1e-9
+
+
+def test_config5_full_size_on_gpu_counts(mods, tmp_path):
+    """BASELINE config 5 at its stated size -- 4 deleterious group instances, 25k + 25k samples x 1M SNPs -- with the
+    per-row case / control allele counts taken on the GPU from the packed matrix (dnaf_allele_counts)."""
+    pop, RowGenerator = mods
+    cfg = tmp_path / "four_groups.yml"
+    cfg.write_text(
+        "one_of_three:\n  mutation_weights: [1, 1, 1]\n  num_instances: 2\n  population_weight: 1\n  max_minor_allele_freq: 0.40\n"
+        "all_of_two:\n  mutation_weights: [0.5, 0.5]\n  num_instances: 1\n  population_weight: 2\n  min_minor_allele_freq: 0.02\n"
+        "single:\n  mutation_weights: [1]\n  num_instances: 1\n  population_weight: 4\n")
+    numpy.random.seed(55)
+    random.seed(55)
+    M, n_case, n_ctrl = 1_000_000, 25_000, 25_000
+    tb = pop.generate_snp_table(M, min_maf=0.01)
+    groups = pop.pick_deleterious(tb, str(cfg))
+    st = pop.build_samples(groups, n_ctrl, n_case, 0.5, str(tmp_path))
+    counts = np.zeros((M, 2), dtype=np.int64)
+    tile = 100_000
+    with RowGenerator(device=0, seed=501) as g:
+        g.set_samples(st)
+        g.set_snps(tb)
+        for b in range(0, M, tile):
+            g.ctx.generate(b, tile, 2)  # packed only
+            counts[b: b + tile] = g.ctx.allele_counts(tile)
+            if b == 0:  # the GPU counts agree with counting the packed words on the host
+                packed = g.ctx.read_packed(tile, g.words_per_row)[:2000]
+                bits = np.unpackbits(packed.view(np.uint8), axis=1, bitorder="little")[:, : 2 * (n_case + n_ctrl)]
+                per_sample = bits.reshape(2000, -1, 2).sum(axis=2)
+                assert np.array_equal(per_sample[:, :n_ctrl].sum(axis=1), counts[:2000, 0])
+                assert np.array_equal(per_sample[:, n_ctrl:].sum(axis=1), counts[:2000, 1])
+    male = (st.flags & 1).astype(bool)
+    n_male_ctrl, n_male_case = int(male[:n_ctrl].sum()), int(male[n_ctrl:].sum())
+    cls = tb.chrom_class
+    maf = 1 - tb.cum[:, 0]
+    # alleles present per row among controls / cases: 2 per diploid cell, 1 per haploid cell, 0 for '.'
+    def denom(n, n_male):
+        return np.select([cls == 0, cls == 1, cls == 2], [2 * n, 2 * n - n_male, n_male], default=n).astype(float)
+
+    ctrl_af = counts[:, 0] / denom(n_ctrl, n_male_ctrl)
+    case_af = counts[:, 1] / denom(n_case, n_male_case)
+    forced_ids = set(int(s) for grp in groups.values() for s in grp.deleterious)
+    is_forced = np.isin(tb.snp_id, list(forced_ids))
+    assert is_forced.sum() == len(forced_ids) == 3 * 2 + 2 + 1
+    plain = ~is_forced
+    # ordinary rows: controls and cases both sit on the row's MAF; z-scores behave like a standard normal
+    se = np.sqrt(maf * (1 - maf) / denom(n_ctrl, n_male_ctrl))
+    z_ctrl = (ctrl_af - maf)[plain] / se[plain]
+    z_case = ((case_af - maf) / np.sqrt(maf * (1 - maf) / denom(n_case, n_male_case)))[plain]
+    for z in (z_ctrl, z_case):
+        assert abs(z.mean()) < 0.01 and abs(z.std() - 1) < 0.01 and np.abs(z).max() < 6.5
+    # deleterious rows: cases are skewed by the share of cases the configuration gives the SNP
+    total_w = 1 + 1 + 2 + 4
+    for name, grp in groups.items():
+        share = grp.population_weight / total_w
+        frac = {"one_of_three": 1 / 3, "all_of_two": 1.0, "single": 1.0}[name.rsplit("-", 1)[0]]
+        for sid in grp.deleterious:
+            j = int(np.flatnonzero(tb.snp_id == sid)[0])
+            if cls[j] == 2:
+                continue
+            q = share * frac
+            want = maf[j] + q * (1 - maf[j])
+            assert abs(ctrl_af[j] - maf[j]) < 5 * se[j]
+            assert abs(case_af[j] - want) < 5 * (np.sqrt(q * (1 - q) / n_case) + np.sqrt(maf[j] / n_case))
