@@ -198,3 +198,25 @@ def test_tile_larger_than_4_gib(RowGenerator, oracle):
             assert text.tobytes() == want
         packed = g.ctx.read_packed(n, g.words_per_row)
         assert np.array_equal(packed[n - 48:], want_packed)
+
+
+@pytest.mark.parametrize("S,n_rows", [(1_000_003, 6), (4, 300_000)])
+def test_extreme_shapes(RowGenerator, oracle, S, n_rows):
+    """Very wide rows (a million samples: many segments per row, 4 MB lines) and very many narrow rows."""
+    from dna_factory_amd.tables import SampleTable, SnpTable
+
+    rs = np.random.RandomState(S % 1000)
+    flags = (rs.rand(S) <= 0.5).astype(np.uint8) | (np.arange(S) < S // 2).astype(np.uint8) * 2
+    st = SampleTable(flags)
+    cum = np.ones((n_rows, 4))
+    cum[:, 0] = 1 - 0.005 * rs.randint(1, 100, n_rows)
+    chrom = np.array([b"7", b"X", b"Y", b"MT"])[np.arange(n_rows) % 4].astype("S2")
+    tb = SnpTable(np.arange(1, n_rows + 1), chrom, np.arange(n_rows) + 1, np.full(n_rows, b"C", dtype="S1"),
+                  np.full(n_rows, b"T", dtype="S1"), np.full(n_rows, 2, np.uint8), cum)
+    sex, ctrl, doff, dids = oracle.sample_arrays_from_table(st.flags, st.forced_ids, st.carrier_off, st.carrier_idx)
+    with RowGenerator(device=0, seed=3) as g:
+        g.set_samples(st)
+        g.set_snps(tb)
+        text, off, packed = g.generate()
+    bad = oracle.verify_threads(oracle.table_records(tb), sex, ctrl, doff, dids, 3, 8, text, off, packed)
+    assert bad is None, "row %s differs" % bad
