@@ -98,36 +98,34 @@ __device__ __forceinline__ uint32_t pick53(uint64_t r, uint64_t t0, uint64_t t1,
 __device__ __forceinline__ uint64_t roll53(uint32_t a, uint32_t b) { return ((uint64_t)(a >> 5) << 26) | (uint64_t)(b >> 6); }
 
 // One wave: the next block.  The state is regenerated in place in the three dependent phases of the
-// recurrence (words 0..226 need only old words; 227..453 need the new words 0..226; 454..623 need the
-// new words 227..396, and word 623 the new word 0).  Inside a phase nothing depends on anything else
-// written in that phase, so all of a phase's LDS reads are issued before its writes: three latency
+// recurrence (words 0..226 need only old words; 227..453 need the new words 0..226; 454..622 need the
+// new words 227..395, and word 623 the new words 396 and 0).  Inside a phase nothing depends on anything
+// else written in that phase, so all of a phase's LDS reads are issued before its writes: three latency
 // exposures per block instead of ten.  Each new word is also tempered into the output ring at
-// ring[(head + i) mod MT_RING].
+// ring[(head + i) mod MT_RING].  The code is branch-free: lanes past the end of a phase read a valid
+// word and write to a spare slot behind each array.
 template <uint32_t LO, uint32_t HI>
 __device__ __forceinline__ void mt_wave_phase(uint32_t* st, uint32_t* ring, uint32_t head, uint32_t lane)
 {
     constexpr uint32_t STEPS = (HI - LO + 63u) / 64u;
+    constexpr bool OLD_M = HI <= MTN - MTM; // word i + 397 is still the old one
     uint32_t v[STEPS];
 #pragma unroll
     for (uint32_t s = 0; s < STEPS; ++s) {
-        const uint32_t i = LO + 64u * s + lane;
-        v[s] = 0;
-        if (i < HI) {
-            const uint32_t i1 = i + 1u == MTN ? 0u : i + 1u;
-            const uint32_t im = i + MTM < MTN ? i + MTM : i + MTM - MTN;
-            v[s] = st[im] ^ mt_twist(st[i], st[i1]);
-        }
+        const uint32_t i = min(LO + 64u * s + lane, HI - 1u);
+        const uint32_t i1 = HI == MTN ? 0u : i + 1u; // only the phase of word 623 wraps
+        const uint32_t im = OLD_M ? i + MTM : i - (MTN - MTM);
+        v[s] = st[im] ^ mt_twist(st[i], st[i1]);
     }
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (uint32_t s = 0; s < STEPS; ++s) {
         const uint32_t i = LO + 64u * s + lane;
-        if (i < HI) {
-            st[i] = v[s];
-            uint32_t h = head + i;
-            h = h >= MT_RING ? h - MT_RING : h;
-            ring[h] = mt_temper(v[s]);
-        }
+        const bool ok = i < HI;
+        uint32_t h = head + i;
+        h = h >= MT_RING ? h - MT_RING : h;
+        st[ok ? i : MTN] = v[s];                 // st[MTN] and ring[MT_RING] are spare slots
+        ring[ok ? h : MT_RING] = mt_temper(v[s]);
     }
     __builtin_amdgcn_wave_barrier();
 }
@@ -143,8 +141,8 @@ __device__ __forceinline__ void mt_wave_next_block(uint32_t* st, uint32_t* ring,
 template <bool TEXT, bool PACKED>
 __global__ __launch_bounds__(64) void mt_rowgen_kernel(const MtGenParams mp)
 {
-    __shared__ uint32_t st[MTN];
-    __shared__ __attribute__((aligned(16))) uint32_t ring[MT_RING];
+    __shared__ uint32_t st[MTN + 1];
+    __shared__ __attribute__((aligned(16))) uint32_t ring[MT_RING + 4];
     const GenParams& p = mp.g;
     const uint32_t lane = threadIdx.x;
     const uint64_t wave = blockIdx.x;
