@@ -294,6 +294,41 @@ __device__ __forceinline__ void row_segment(const SegCtx& c, uint32_t cls, uint3
     const uint32_t g_last = c.S ? (c.S - 1u) / 4u : 0u;
     const uint32_t g_fast = min(g_end, g_last);
     uint32_t gb = g_begin;
+    if (cls == 0u && !MULTI) {
+        // biallelic autosome (almost every row): the row's last group rides in the same pass -- its lane draws
+        // the same two Philox blocks and only stores differently -- so short rows need one trip, not two
+        for (; gb < g_end; gb += 64u) {
+            const uint32_t g = gb + lane;
+            if (g < g_end) {
+                uint32_t d0, d1, d2, d3;
+                biallelic_cells(c, g, d0, d1, d2, d3);
+                const uint32_t D = biallelic_spread(d0, d1, d2, d3);
+                uint32_t pk = D | (D >> 15);
+                if (g < g_fast) {
+                    if (TEXT) {
+                        const uint4 w = make_uint4(d0, d1, d2, d3);
+                        store_unaligned<16>(c.cells + 16ull * g, &w);
+                    }
+                } else { // the group with the row's last sample: newline instead of the last tab, maybe < 4 samples
+                    const uint32_t nvalid = c.S - 4u * g;
+                    const uint32_t fix = 0x0A000000u - 0x09000000u;
+                    if (TEXT) {
+                        uint8_t* dst = c.cells + 16ull * g;
+                        const uint32_t w0 = d0 + (nvalid == 1u ? fix : 0u), w1 = d1 + (nvalid == 2u ? fix : 0u);
+                        const uint32_t w2 = d2 + (nvalid == 3u ? fix : 0u), w3 = d3 + (nvalid == 4u ? fix : 0u);
+                        store_unaligned<4>(dst, &w0);
+                        if (nvalid > 1u) store_unaligned<4>(dst + 4, &w1);
+                        if (nvalid > 2u) store_unaligned<4>(dst + 8, &w2);
+                        if (nvalid > 3u) store_unaligned<4>(dst + 12, &w3);
+                    }
+                    pk &= (1u << (2u * nvalid)) - 1u; // codes of samples past the end stay 0
+                }
+                if (PACKED) c.prow[g] = (uint8_t)pk;
+            }
+        }
+        if (PACKED && g_stop > g_end && g_end + lane < g_stop) c.prow[g_end + lane] = 0; // pad bytes (at most 3)
+        return;
+    }
     if (cls == 0u) {
         for (; gb < g_fast; gb += 64u)
             if (gb + lane < g_fast) autosome_fast<TEXT, PACKED, MULTI>(c, gb + lane);
