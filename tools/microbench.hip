@@ -92,6 +92,21 @@ __global__ __launch_bounds__(256) void k_store1(uint8_t* dst, uint64_t bytes_per
     for (uint64_t o = 0; o + 64 <= bytes_per_wave; o += 64) { v += lane; p[o] = v; }
 }
 
+// 64 contiguous bytes per wave-instruction, written by 16 lanes as dwords / by 4 lanes as dwordx4
+__global__ __launch_bounds__(256) void k_store_sparse(uint8_t* dst, uint64_t bytes_per_wave, int lanes)
+{
+    const uint32_t lane = threadIdx.x & 63;
+    const uint64_t wave = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    uint8_t* p = dst + wave * bytes_per_wave;
+    uint32_t v = 3;
+    for (uint64_t o = 0; o + 64 <= bytes_per_wave; o += 64) {
+        v += lane;
+        if (lanes == 16) { if ((lane & 3) == 0) *reinterpret_cast<uint32_t*>(p + o + lane) = v; }
+        else if (lanes == 4) { if ((lane & 15) == 0) *reinterpret_cast<uint4*>(p + o + lane) = make_uint4(v, v, v, v); }
+        else p[o + lane] = (uint8_t)v;
+    }
+}
+
 int main()
 {
     hipEvent_t e0, e1;
@@ -160,6 +175,15 @@ int main()
             CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms, e0, e1));
         }
         printf("store1  bytes/wave=%llu: %.3f ms  %.1f GB/s\n", (unsigned long long)bpw1, ms, (double)(1ull << 30) / (ms * 1e-3) / 1e9);
+    }
+    for (int lanes : {64, 16, 4}) {
+        const uint64_t bpw1 = 8192, waves1 = (1ull << 30) / bpw1;
+        for (int rep = 0; rep < 2; ++rep) {
+            CK(hipEventRecord(e0));
+            hipLaunchKernelGGL(k_store_sparse, dim3((uint32_t)(waves1 / 4)), dim3(256), 0, 0, d_buf, bpw1, lanes);
+            CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms, e0, e1));
+        }
+        printf("store 64B/instr by %2d lanes: %.3f ms  %.1f GB/s\n", lanes, ms, (double)(1ull << 30) / (ms * 1e-3) / 1e9);
     }
     CK(hipDeviceSynchronize());
     printf("done\n");
