@@ -221,6 +221,7 @@ int dnaf_set_samples(dnaf_ctx* c, const uint8_t* flags, uint64_t n_samples)
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     c->have_samples = c->have_snps = c->have_output = false;
+    c->mt_valid = false; // wave start states depend on the number of samples
     c->n_slots = 0;
     c->slot_of.clear();
     dev_free(c->d_forced);

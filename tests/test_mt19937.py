@@ -141,3 +141,17 @@ def test_gpu_mt19937_shard_offset(RowGenerator, oracle):
         g.set_snps(snps[78:], rng_row0=78)
         t, _, _ = g.generate()
     assert t.tobytes() == whole[int(off[78]):]
+
+
+@pytest.mark.gpu
+def test_gpu_mt19937_new_sample_table_invalidates_cached_states(RowGenerator, oracle):
+    """Wave start states depend on the number of samples; a context reused with another sample table must rebuild them."""
+    rs = np.random.RandomState(41)
+    with RowGenerator(device=0, seed=321, rng="mt19937") as g:
+        for S in (52, 100, 52):
+            snps, samples = random_case(rs, 78, S)
+            want, _, _ = _oracle_mt(oracle, snps, samples, 321)
+            g.set_samples(samples)
+            g.set_snps(snps)
+            t, _, _ = g.generate()
+            assert t.tobytes() == want
