@@ -155,3 +155,34 @@ def test_gpu_mt19937_new_sample_table_invalidates_cached_states(RowGenerator, or
             g.set_snps(snps)
             t, _, _ = g.generate()
             assert t.tobytes() == want
+
+
+@pytest.mark.gpu
+def test_dropin_write_vcf_snps_with_reference_shaped_objects(RowGenerator, oracle):
+    """The INTEGRATION.md stub: objects shaped like the reference's SampleInfo / SNPTuples, a writable sink, and the
+    parent's numpy stream handed over at the point where the reference forks its worker."""
+    import io
+
+    class SampleInfo:  # pop_factory.py:47-71
+        def __init__(self, fid, iid, sex, ctrl, dele):
+            self.family_id, self.person_id, self.sex, self.is_control, self.deleterious_snps = fid, iid, sex, ctrl, dele
+
+        def is_male(self):
+            return self.sex == 1
+
+    class SNPTuples:  # pop_factory.py:74-85
+        def __init__(self, sid, chrom, pos, tuples):
+            self.id, self.chromosome, self.position, self.tuples = sid, chrom, pos, tuples
+
+    rs = np.random.RandomState(77)
+    snps, samples = random_case(rs, 90, 60)
+    fam = [SampleInfo(i + 1, 100001 + i, sx, c, None if c else {k: 1.0 for k in (car or [])}) for i, (sx, c, car) in enumerate(samples)]
+    ref_snps = [SNPTuples(*s) for s in snps]
+    np.random.seed(235959)
+    np.random.rand(len(fam))  # generate_fam_file drew the sexes before the fork (pop_factory.py:352)
+    state = np.random.get_state()
+    want, _, _ = _oracle_mt(oracle, snps, samples, 0, mt_state=(state[1].astype(np.uint32), int(state[2])))
+    sink = io.BytesIO()
+    with RowGenerator(device=0, rng="mt19937", mt_state=state[1:3]) as g:
+        assert g.write_vcf_snps(fam, ref_snps, sink) == 90
+    assert sink.getvalue() == want
