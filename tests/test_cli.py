@@ -56,6 +56,20 @@ def _run_cli(args, cwd=REPO):
                           capture_output=True, text=True, timeout=600)
 
 
+def _expected_body_inputs(outdir):
+    """(None, samples) rebuilt from population.fam and pop_deleterious.txt."""
+    carried = {}
+    for line in open(os.path.join(outdir, "pop_deleterious.txt")):
+        parts = line.rstrip("\n").split("\t")
+        carried[int(parts[0])] = [int(x[2:]) for x in parts[2:] if x]
+    samples = []
+    for line in open(os.path.join(outdir, "population.fam")):
+        fid, iid, _, _, sex, pheno = line.split("\t")[:6]
+        ctrl = pheno == "1"
+        samples.append((int(sex), ctrl, None if ctrl else carried[int(iid)]))
+    return None, samples
+
+
 def _expected_body(outdir, seed, orc):
     """Rebuild the worker's inputs from the side files the run wrote, and run the CPU oracle on them."""
     snps = []
@@ -171,3 +185,27 @@ def test_cli_mt19937_continues_the_numpy_stream(oracle, tmp_path):
 def test_cli_refuses_the_database_path(tmp_path):
     r = _run_cli(["-s", "1", "-c", "1", "-l", "--outdir", str(tmp_path / "x")])
     assert r.returncode != 0 and "not supported" in (r.stderr + r.stdout)
+
+
+@pytest.mark.gpu
+def test_cli_chunk_restart_matches_the_reference_chunking(oracle, tmp_path):
+    """--compat-chunk-restart: from 2M SNPs up the reference forks fresh workers per work chunk, so every chunk draws
+    from the start of the stream again.  Checked on 2,000,001 SNPs x 4 samples against per-chunk oracle runs."""
+    out = tmp_path / "chunks"
+    r = _run_cli(["-s", "2", "-c", "2", "-x", "2000001", "--seed", "77", "--compat-chunk-restart", "--outdir", str(out)])
+    assert r.returncode == 0, r.stderr
+    snps = []
+    for line in gzip.open(out / "snps.json.gz", "rt"):
+        o = json.loads(line)
+        snps.append((o["id"], o["chromosome"], o["position"], list(o["tuples"].items())))
+    _, samples = _expected_body_inputs(str(out))
+    rec = oracle.snp_records(snps)
+    sex, ctrl, off, ids = oracle.sample_arrays(samples)
+    body = gzip.open(out / "population.vcf.gz", "rb").read().split(b"#CHROM", 1)[1].split(b"\n", 1)[1]
+    pos = 0
+    for lo, hi in ((0, 1000000), (1000000, 2000001)):
+        want, _, _ = oracle.generate(rec[lo:hi], sex, ctrl, off, ids, rng_mode=oracle.RNG_PHILOX, seed=77, rng_row0=0,
+                                     want_packed=False)
+        assert body[pos: pos + len(want)] == want
+        pos += len(want)
+    assert pos == len(body)
