@@ -91,21 +91,31 @@ def _generate_shard(device, seed, rng, mt_state, st, tb, row_lo, row_hi, rng_row
     from . import capi
     from .rowgen import RowGenerator
 
-    with RowGenerator(device=device, seed=seed, rng=rng, mt_state=mt_state) as gen:
+    from concurrent.futures import ThreadPoolExecutor
+
+    with RowGenerator(device=device, seed=seed, rng=rng, mt_state=mt_state) as gen, ThreadPoolExecutor(max_workers=1) as writer:
         gen.set_samples(st)
         gen.set_snps(tb.slice(row_lo, row_hi), rng_row0=rng_row_lo)
         n = row_hi - row_lo
         q = gen.row_quantum
         tile_rows = max(q, tile_rows // q * q)
+        pending = None  # the sink drains tile k on the writer thread while the GPU produces tile k+1
         for b in range(0, n, tile_rows):
             m = min(tile_rows, n - b)
             gen.ctx.generate(b, m, capi.OUT_TEXT)
             if host_bgzf:
-                sink.write(gen.ctx.fetch_text())
+                view, put = gen.ctx.fetch_text(), sink.write
             else:
                 gen.ctx.bgzf_compress(reuse_tables=b > 0)
-                sink.write_members(gen.ctx.fetch_bgzf())  # pinned staging buffer: consumed before the next fetch
+                view, put = gen.ctx.fetch_bgzf(), sink.write_members
+            # the library alternates two pinned staging buffers: tile k's stays valid through the fetch of tile k+1,
+            # so its write only has to finish before tile k+2 is fetched
+            if pending is not None:
+                pending.result()
+            pending = writer.submit(put, view)
             progress(m)
+        if pending is not None:
+            pending.result()
 
 
 def write_vcf(path, header, st, tb, seed, rng, devices, compresslevel, tile_rows=0, threads=0, host_bgzf=False,

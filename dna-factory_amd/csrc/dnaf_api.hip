@@ -98,8 +98,9 @@ struct dnaf_ctx {
     float bgzf_ms = 0.f;
 
     // pinned host staging for device -> host copies at PCIe rate
-    void* h_pinned = nullptr;
-    uint64_t pinned_cap = 0;
+    void* h_pinned[2] = {nullptr, nullptr}; // alternate, so that one fetched range stays valid while the next is produced
+    uint64_t pinned_cap[2] = {0, 0};
+    int pinned_next = 0;
 
     // tuning
     uint32_t seg_iters = 32;
@@ -189,7 +190,7 @@ int dnaf_destroy(dnaf_ctx* c)
     dev_free(c->d_prefix);
     dev_free(c->d_text);
     dev_free(c->d_packed);
-    if (c->h_pinned) (void)hipHostFree(c->h_pinned);
+    for (void* hp : c->h_pinned) if (hp) (void)hipHostFree(hp);
     dev_free(c->d_counts);
     dev_free(c->d_thr53);
     dev_free(c->d_mt_base);
@@ -933,18 +934,20 @@ int dnaf_read_bgzf(dnaf_ctx* c, void* dst, uint64_t dst_cap, uint64_t* n_bytes)
 static int fetch_pinned(dnaf_ctx* c, const void* d_src, uint64_t n, const void** host)
 {
     HIP_TRY(c, hipSetDevice(c->device));
-    if (n > c->pinned_cap) {
+    const int k = c->pinned_next;
+    c->pinned_next ^= 1;
+    if (n > c->pinned_cap[k]) {
         HIP_TRY(c, hipStreamSynchronize(c->stream));
-        if (c->h_pinned) (void)hipHostFree(c->h_pinned);
-        c->h_pinned = nullptr;
-        c->pinned_cap = 0;
+        if (c->h_pinned[k]) (void)hipHostFree(c->h_pinned[k]);
+        c->h_pinned[k] = nullptr;
+        c->pinned_cap[k] = 0;
         const uint64_t want = n + n / 4 + 4096;
-        HIP_TRY(c, hipHostMalloc(&c->h_pinned, want, hipHostMallocDefault));
-        c->pinned_cap = want;
+        HIP_TRY(c, hipHostMalloc(&c->h_pinned[k], want, hipHostMallocDefault));
+        c->pinned_cap[k] = want;
     }
-    if (n) HIP_TRY(c, hipMemcpyAsync(c->h_pinned, d_src, n, hipMemcpyDeviceToHost, c->stream));
+    if (n) HIP_TRY(c, hipMemcpyAsync(c->h_pinned[k], d_src, n, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    *host = c->h_pinned;
+    *host = c->h_pinned[k];
     return DNAF_OK;
 }
 

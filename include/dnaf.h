@@ -162,8 +162,9 @@ int dnaf_device_buffers(dnaf_ctx* ctx, void** d_text, uint64_t* text_bytes, void
 int dnaf_bgzf_compress(dnaf_ctx* ctx, uint32_t flags, uint64_t* n_bytes);
 int dnaf_read_bgzf(dnaf_ctx* ctx, void* dst, uint64_t dst_cap, uint64_t* n_bytes);
 /* The same data through the context's pinned staging buffer (DMA at PCIe rate instead of a pageable
- * copy): *host points at n_bytes bytes owned by the library, valid until the next dnaf_fetch_* /
- * dnaf_destroy on this context.  Synchronises. */
+ * copy): *host points at n_bytes bytes owned by the library.  Two staging buffers alternate, so the
+ * pointer stays valid through the next dnaf_fetch_* call and is reused by the one after it (a writer
+ * thread can drain range k while range k+1 is generated and fetched).  Synchronises. */
 int dnaf_fetch_bgzf(dnaf_ctx* ctx, const void** host, uint64_t* n_bytes);
 int dnaf_fetch_text(dnaf_ctx* ctx, const void** host, uint64_t* n_bytes);
 /* Summed device time of the encoder's kernels in the last dnaf_bgzf_compress (HIP events). */
