@@ -24,6 +24,7 @@ MAX_ALLELES = 4
 RNG_PHILOX, RNG_MT19937 = 0, 1
 OUT_TEXT, OUT_PACKED = 1, 2
 BGZF_REUSE_TABLES = 1
+BGZF_TEXT_DOMAIN = 2
 
 # every symbol include/dnaf.h declares
 SYMBOLS = [
@@ -330,10 +331,12 @@ class Context:
         self._check(lib.dnaf_read_packed(self._h, ptr(flat), buf.size, ctypes.byref(got)))
         return buf
 
-    def bgzf_compress(self, reuse_tables=False):
-        """Compress the last generated text on the GPU; returns the number of BGZF bytes."""
+    def bgzf_compress(self, reuse_tables=False, text_domain=False):
+        """Compress the last generated text on the GPU; returns the number of BGZF bytes.  Members in biallelic
+        autosome rows are made from the genotype matrix when it was generated too (text_domain=True: never)."""
         n = ctypes.c_uint64(0)
-        self._check(lib.dnaf_bgzf_compress(self._h, BGZF_REUSE_TABLES if reuse_tables else 0, ctypes.byref(n)))
+        flags = (BGZF_REUSE_TABLES if reuse_tables else 0) | (BGZF_TEXT_DOMAIN if text_domain else 0)
+        self._check(lib.dnaf_bgzf_compress(self._h, flags, ctypes.byref(n)))
         return n.value
 
     def read_bgzf(self, n_bytes):

@@ -102,7 +102,7 @@ def _generate_shard(device, seed, rng, mt_state, st, tb, row_lo, row_hi, rng_row
         pending = None  # the sink drains tile k on the writer thread while the GPU produces tile k+1
         for b in range(0, n, tile_rows):
             m = min(tile_rows, n - b)
-            gen.ctx.generate(b, m, capi.OUT_TEXT)
+            gen.ctx.generate(b, m, capi.OUT_TEXT if host_bgzf else capi.OUT_TEXT | capi.OUT_PACKED)
             if host_bgzf:
                 view, put = gen.ctx.fetch_text(), sink.write
             else:

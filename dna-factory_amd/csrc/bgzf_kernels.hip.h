@@ -47,6 +47,7 @@ struct BgzfParams {
     uint32_t* large_list;    // [0] = number of members that need the large buffer, [1..] their block indices
     const uint64_t* offsets; // [n_blocks+1] exclusive scan of sizes
     uint8_t* out;
+    const uint8_t* fast;     // [n_blocks] or null: 1 = the genotype-domain encoder (gtz_kernels.hip.h) made this member
 };
 
 __device__ __forceinline__ uint32_t block_len(const BgzfParams& p, uint32_t b)
@@ -268,6 +269,7 @@ __global__ __launch_bounds__(BGZF_THREADS) void bgzf_size(const BgzfParams p)
     __shared__ uint32_t crc_tab[4][256];
     __shared__ uint32_t scratch[BGZF_WAVES];
     const uint32_t b = blockIdx.x, tid = threadIdx.x;
+    if (p.fast && p.fast[b]) return;
     load_code_table(p, tab);
     crc_tab[tid >> 8][tid & 255u] = p.tables->crc_table[tid >> 8][tid & 255u];
     const uint32_t N = block_len(p, b);
@@ -355,6 +357,7 @@ __global__ __launch_bounds__(BGZF_THREADS, OUT_BYTES == BGZF_OUT_SMALL ? 8 : 4) 
     __shared__ uint32_t scratch[BGZF_WAVES];
     const uint32_t tid = threadIdx.x;
     const uint32_t b = OUT_BYTES == BGZF_OUT_LARGE ? p.large_list[1u + blockIdx.x] : blockIdx.x;
+    if (p.fast && p.fast[b]) return;
     const uint32_t N = block_len(p, b);
     const uint8_t* blk = p.text + (uint64_t)b * BGZF_IN;
     uint8_t* dst = p.out + p.offsets[b];

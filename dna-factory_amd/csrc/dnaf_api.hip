@@ -7,6 +7,7 @@
 #include "../../include/dnaf.h"
 #include "rowgen_kernels.hip.h"
 #include "bgzf_kernels.hip.h"
+#include "gtz_kernels.hip.h"
 #include "mt_jump.h"
 #include "mt_kernels.hip.h"
 
@@ -96,6 +97,14 @@ struct dnaf_ctx {
     bool have_bgzf = false;
     hipEvent_t zev[2] = {nullptr, nullptr};
     float bgzf_ms = 0.f;
+    // ... its genotype-domain part (members made from the packed matrix)
+    dnaf::GtzTables* d_gtz_tables = nullptr;
+    uint32_t* d_gtz_hist = nullptr;
+    uint32_t* d_member_row = nullptr;
+    uint8_t* d_fast = nullptr;
+    uint8_t* d_stage = nullptr;
+    uint64_t stage_cap = 0;
+    bool have_gtz_tables = false;
 
     // pinned host staging for device -> host copies at PCIe rate
     void* h_pinned[2] = {nullptr, nullptr}; // alternate, so that one fetched range stays valid while the next is produced
@@ -205,6 +214,11 @@ int dnaf_destroy(dnaf_ctx* c)
     dev_free(c->d_large);
     dev_free(c->d_offsets);
     dev_free(c->d_bgzf);
+    dev_free(c->d_gtz_tables);
+    dev_free(c->d_gtz_hist);
+    dev_free(c->d_member_row);
+    dev_free(c->d_fast);
+    dev_free(c->d_stage);
     for (hipEvent_t e : c->zev) if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : c->evs) (void)hipEventDestroy(e);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -814,7 +828,9 @@ int dnaf_bgzf_compress(dnaf_ctx* c, uint32_t flags, uint64_t* n_bytes)
 {
     if (!c) return DNAF_ERR_BAD_ARG;
     if (!c->have_output || !(c->last_what & DNAF_OUT_TEXT)) return fail(c, DNAF_ERR_STATE, "dnaf_bgzf_compress: no text was generated");
-    if (flags & ~DNAF_BGZF_REUSE_TABLES) return fail(c, DNAF_ERR_BAD_ARG, "dnaf_bgzf_compress: flags = %u", flags);
+    if (flags & ~(DNAF_BGZF_REUSE_TABLES | DNAF_BGZF_TEXT_DOMAIN)) return fail(c, DNAF_ERR_BAD_ARG, "dnaf_bgzf_compress: flags = %u", flags);
+    // members that lie in biallelic autosome rows are made from the genotype matrix when it was generated too
+    const bool gtz = (c->last_what & DNAF_OUT_PACKED) && !(flags & DNAF_BGZF_TEXT_DOMAIN) && c->S >= 2;
     HIP_TRY(c, hipSetDevice(c->device));
     const uint64_t tbytes = c->h_text_off[(size_t)(c->last_begin + c->last_rows)] - c->h_text_off[(size_t)c->last_begin];
     c->have_bgzf = false;
@@ -835,7 +851,11 @@ int dnaf_bgzf_compress(dnaf_ctx* c, uint32_t flags, uint64_t* n_bytes)
         dev_free(c->d_crcs);
         dev_free(c->d_large);
         dev_free(c->d_offsets);
+        dev_free(c->d_member_row);
+        dev_free(c->d_fast);
         c->blocks_cap = 0;
+        HIP_TRY(c, hipMalloc((void**)&c->d_member_row, (uint64_t)nb * sizeof(uint32_t)));
+        HIP_TRY(c, hipMalloc((void**)&c->d_fast, (uint64_t)nb));
         HIP_TRY(c, hipMalloc((void**)&c->d_crcs, (uint64_t)nb * sizeof(uint32_t)));
         HIP_TRY(c, hipMalloc((void**)&c->d_large, ((uint64_t)nb + 1) * sizeof(uint32_t)));
         HIP_TRY(c, hipMalloc((void**)&c->d_sizes, (uint64_t)nb * sizeof(uint32_t)));
@@ -856,7 +876,61 @@ int dnaf_bgzf_compress(dnaf_ctx* c, uint32_t flags, uint64_t* n_bytes)
     p.large_list = c->d_large;
     p.offsets = c->d_offsets;
     p.out = nullptr;
+    p.fast = gtz ? c->d_fast : nullptr;
     float ms_total = 0.f, ms = 0.f;
+    dnaf::GtzParams g;
+    if (gtz) {
+        if (!c->d_gtz_tables) HIP_TRY(c, hipMalloc((void**)&c->d_gtz_tables, sizeof(dnaf::GtzTables)));
+        if (!c->d_gtz_hist) HIP_TRY(c, hipMalloc((void**)&c->d_gtz_hist, dnaf::GTZ_NCLASS * dnaf::GTZ_NSYM * sizeof(uint32_t)));
+        const uint64_t want = (uint64_t)nb * dnaf::GTZ_STRIDE;
+        if (want > c->stage_cap) {
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            dev_free(c->d_stage);
+            c->stage_cap = 0;
+            HIP_TRY(c, hipMalloc((void**)&c->d_stage, want));
+            c->stage_cap = want;
+        }
+        g.recs = c->d_recs;
+        g.prefix = c->d_prefix;
+        g.packed = (const uint32_t*)c->d_packed;
+        g.text_base = c->h_text_off[(size_t)c->last_begin];
+        g.row_begin = c->last_begin;
+        g.n_rows = c->last_rows;
+        g.n_bytes = tbytes;
+        g.n_blocks = nb;
+        g.S = (uint32_t)c->S;
+        g.W = c->W;
+        g.sample_step = nb > 2048 ? nb / 2048 : 1;
+        g.tables = c->d_gtz_tables;
+        g.member_row = c->d_member_row;
+        g.hist = c->d_gtz_hist;
+        g.sizes = c->d_sizes;
+        g.fast = c->d_fast;
+        g.stage = c->d_stage;
+        g.offsets = c->d_offsets;
+        g.out = nullptr;
+        HIP_TRY(c, hipEventRecord(c->zev[0], c->stream));
+        hipLaunchKernelGGL(dnaf::gtz_locate, dim3((nb + 255) / 256), dim3(256), 0, c->stream, g);
+        HIP_TRY(c, hipGetLastError());
+        if (!(c->have_gtz_tables && (flags & DNAF_BGZF_REUSE_TABLES))) {
+            static thread_local uint32_t h[dnaf::GTZ_NCLASS * dnaf::GTZ_NSYM];
+            HIP_TRY(c, hipMemsetAsync(c->d_gtz_hist, 0, sizeof h, c->stream));
+            hipLaunchKernelGGL((dnaf::gtz_encode<true>), dim3((nb + g.sample_step - 1) / g.sample_step), dim3(dnaf::GTZ_THREADS), 0, c->stream, g);
+            HIP_TRY(c, hipGetLastError());
+            HIP_TRY(c, hipMemcpyAsync(h, c->d_gtz_hist, sizeof h, hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            static thread_local dnaf::GtzTables gt;
+            if (!dnaf::gtz_build_tables(h, &gt)) return fail(c, DNAF_ERR_UNSUPPORTED, "dnaf_bgzf_compress: block header does not fit");
+            HIP_TRY(c, hipMemcpy(c->d_gtz_tables, &gt, sizeof gt, hipMemcpyHostToDevice));
+            c->have_gtz_tables = true;
+        }
+        hipLaunchKernelGGL((dnaf::gtz_encode<false>), dim3(nb), dim3(dnaf::GTZ_THREADS), 0, c->stream, g);
+        HIP_TRY(c, hipGetLastError());
+        HIP_TRY(c, hipEventRecord(c->zev[1], c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        HIP_TRY(c, hipEventElapsedTime(&ms, c->zev[0], c->zev[1]));
+        ms_total += ms;
+    }
     if (!(c->have_tables && (flags & DNAF_BGZF_REUSE_TABLES))) {
         // 1. token histogram over a sample of blocks -> one Huffman table for the whole range
         uint32_t h[513];
@@ -904,6 +978,11 @@ int dnaf_bgzf_compress(dnaf_ctx* c, uint32_t flags, uint64_t* n_bytes)
     HIP_TRY(c, hipGetLastError());
     if (n_large) {
         hipLaunchKernelGGL((dnaf::bgzf_encode<dnaf::BGZF_OUT_LARGE>), dim3(n_large), dim3(dnaf::BGZF_THREADS), 0, c->stream, p);
+        HIP_TRY(c, hipGetLastError());
+    }
+    if (gtz) {
+        g.out = c->d_bgzf;
+        hipLaunchKernelGGL(dnaf::gtz_compact, dim3(nb), dim3(256), 0, c->stream, g);
         HIP_TRY(c, hipGetLastError());
     }
     HIP_TRY(c, hipEventRecord(c->zev[1], c->stream));

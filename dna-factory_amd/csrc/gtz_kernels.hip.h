@@ -1,0 +1,612 @@
+// gtz_kernels.hip.h -- genotype-domain BGZF encoder (gfx950): BGZF members of the VCF text made from the
+// 2-bit genotype matrix and the rows' fixed columns, without reading the text.
+//
+// A member (61,440 text bytes) that lies in biallelic autosome rows is a known function of the packed
+// matrix: row r's text is its prefix followed by cells "a/b\t" (the last one ends in "\n"), 4 bytes per
+// sample.  One 256-thread workgroup encodes one member:
+//
+//   1. the rows that overlap the member are laid out in LDS ("g space": their 2-bit cells back to back,
+//      word-aligned per row), 960 words instead of 61 KB of text;
+//   2. every 5-cell key (10 bits) is entered into direct-indexed tables -- earliest and latest position
+//      per quarter of the member -- with LDS atomics;
+//   3. each thread tokenises one 64-cell chunk (256 text bytes): where a cell differs from its predecessor
+//      it looks the key up, extends the candidates by XOR / count-trailing-zeros on the 2-bit stream and
+//      takes an LZ77 match when that beats literals; everything else is coded like the text-domain
+//      encoder does (matches at distance 4, literals);  the gaps between rows' cell regions (last cell of
+//      a row, "\n", the next row's fixed columns) are literal spans;
+//   4. bit counts are scanned, the tokens are emitted into an LDS image of the whole member (gzip header,
+//      deflate block, CRC-32, ISIZE) and the image is written to the member's staging slot;  the member
+//      CRC comes from the cells by linearity of the CRC (per-cell unit tables), never from text bytes.
+//
+// bgzf_scan turns sizes into offsets and gtz_compact moves the members to their place in the stream.
+// Members the kernel does not take (other chromosome classes, multi-allelic rows, more than GTZ_MAX_ROWS
+// rows, a body above the slot size) are left to the text-domain encoder (bgzf_kernels.hip.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "bgzf_kernels.hip.h"
+#include "gtz_host.h"
+#include "rowgen_kernels.hip.h"
+
+namespace dnaf {
+
+constexpr uint32_t GTZ_THREADS = 256;
+constexpr uint32_t GTZ_WAVES = GTZ_THREADS / 64;
+constexpr uint32_t GTZ_KEY_CELLS = 5;
+constexpr uint32_t GTZ_KEYS = 1u << (2 * GTZ_KEY_CELLS);
+constexpr uint32_t GTZ_SEGS = 4;          // quarters of the member's g space (4096 cells each)
+constexpr uint32_t GTZ_SEG_SHIFT = 12;
+constexpr uint32_t GTZ_MAX_ROWS = 32;     // rows overlapping one member
+constexpr uint32_t GTZ_MAX_CHUNKS = 304;  // 240 + two partial chunks per row
+constexpr uint32_t GTZ_MAX_ITEMS = 2 * GTZ_THREADS; // chunks + literal spans, two per thread
+constexpr uint32_t GTZ_MAX_FAR = 12;      // LZ77 matches per chunk (64 cells / 5)
+constexpr uint32_t GTZ_CELL_WORDS = BGZF_IN / 64 + 2 * GTZ_MAX_ROWS + 8;
+constexpr uint32_t GTZ_STRIDE = 16384;    // staging slot of a member
+constexpr uint32_t GTZ_OUT_WORDS = GTZ_STRIDE / 4;
+constexpr uint32_t GTZ_MIN_BREAKS = 3;    // an LZ77 match must replace at least this many literal bytes
+static_assert(2 * GTZ_SEGS * GTZ_KEYS >= GTZ_OUT_WORDS, "the member image reuses the key tables");
+
+struct GtzParams {
+    const RowRec* recs;      // [table rows]
+    const uint8_t* prefix;   // prefix blob
+    const uint32_t* packed;  // [n_rows][W] genotype matrix of this call
+    uint64_t text_base;      // recs[row_begin].text_off
+    uint64_t row_begin, n_rows;
+    uint64_t n_bytes;        // text bytes of the call
+    uint32_t n_blocks;
+    uint32_t S, W;
+    uint32_t sample_step;    // gtz_hist: every sample_step-th member
+    const GtzTables* tables;
+    uint32_t* member_row;    // [n_blocks] table row that holds the member's first byte (gtz_locate)
+    uint32_t* hist;          // [GTZ_NCLASS][GTZ_NSYM]
+    uint32_t* sizes;         // [n_blocks] member bytes (same array the text-domain encoder fills for the others)
+    uint8_t* fast;           // [n_blocks] 1 = encoded here
+    uint8_t* stage;          // [n_blocks][GTZ_STRIDE]
+    const uint64_t* offsets; // [n_blocks + 1]
+    uint8_t* out;
+};
+
+// first table row of every member: one thread per member, binary search over text offsets
+__global__ __launch_bounds__(256) void gtz_locate(const GtzParams p)
+{
+    const uint32_t m = blockIdx.x * 256u + threadIdx.x;
+    if (m >= p.n_blocks) return;
+    const uint64_t B = p.text_base + (uint64_t)m * BGZF_IN;
+    uint64_t lo = p.row_begin, hi = p.row_begin + p.n_rows;
+    while (hi - lo > 1) {
+        const uint64_t mid = (lo + hi) >> 1;
+        if (p.recs[mid].text_off <= B) lo = mid;
+        else hi = mid;
+    }
+    p.member_row[m] = (uint32_t)(lo - p.row_begin);
+}
+
+struct GtzShared {
+    uint32_t tabs[2 * GTZ_SEGS * GTZ_KEYS]; // [seg][0 = earliest, 1 = latest + 1][key]; later the member image
+    uint32_t cells[GTZ_CELL_WORDS + 4];
+    uint32_t far[GTZ_MAX_CHUNKS * GTZ_MAX_FAR]; // cell in chunk | cells << 6 | distance in bytes << 13
+    uint32_t lit[256], len[256], dist[32];
+    uint32_t crc_table[256];
+    uint32_t crc_base[GTZ_CHUNK_CELLS + 1], crc_unit_a[GTZ_CHUNK_CELLS], crc_unit_b[GTZ_CHUNK_CELLS];
+    uint32_t hist[GTZ_NSYM];
+    // rows overlapping the member
+    int32_t off[GTZ_MAX_ROWS + 2];     // row start relative to the member's first byte
+    int32_t cs[GTZ_MAX_ROWS + 2];      // first cell's byte, relative to the member
+    uint32_t prefix_off[GTZ_MAX_ROWS + 2];
+    uint32_t kb[GTZ_MAX_ROWS + 2], ke[GTZ_MAX_ROWS + 2]; // cells wholly inside the member, without the row's last cell
+    uint32_t gw[GTZ_MAX_ROWS + 2];     // first g-space word of the row
+    uint32_t kw0[GTZ_MAX_ROWS + 2];    // packed word that g-space word gw[i] is a copy of
+    uint32_t item_base[GTZ_MAX_ROWS + 2];
+    uint32_t chunk_base[GTZ_MAX_ROWS + 2];
+    int32_t span_lo[GTZ_MAX_ROWS + 2], span_hi[GTZ_MAX_ROWS + 2];
+    uint32_t thr0[GTZ_MAX_ROWS + 2];
+    uint8_t cls[GTZ_MAX_ROWS + 2], nall[GTZ_MAX_ROWS + 2];
+    uint32_t scratch[2 * GTZ_WAVES + 4];
+    uint32_t nr, n_items, ok, klass;
+};
+
+// 16 cells of the 2-bit stream starting at g
+__device__ __forceinline__ uint32_t gtz_window(const uint32_t* cells, uint32_t g)
+{
+    const uint32_t w = g >> 4;
+    const uint64_t v = ((uint64_t)cells[w + 1] << 32) | cells[w];
+    return (uint32_t)(v >> (2u * (g & 15u)));
+}
+
+__device__ __forceinline__ uint32_t gtz_len_symbol(uint32_t L)
+{
+    if (L == 258u) return 285u;
+    const uint32_t v = L - 3u;
+    if (v < 8u) return 257u + v;
+    const uint32_t hb = 31u - (uint32_t)__builtin_clz(v);
+    return 257u + 4u * (hb - 1u) + ((v >> (hb - 2u)) & 3u);
+}
+
+// distance symbol, extra-bit count and value of a distance 1..32768
+__device__ __forceinline__ void gtz_dist_symbol(uint32_t d, uint32_t* sym, uint32_t* eb, uint32_t* ev)
+{
+    const uint32_t t = d - 1u;
+    if (t < 4u) { *sym = t; *eb = 0; *ev = 0; return; }
+    const uint32_t hb = 31u - (uint32_t)__builtin_clz(t);
+    *sym = 2u * hb + ((t >> (hb - 1u)) & 1u);
+    *eb = hb - 1u;
+    *ev = t & ((1u << (hb - 1u)) - 1u);
+}
+
+struct GtzCount {
+    const GtzShared* s;
+    uint32_t bits;
+    __device__ __forceinline__ void lit(uint32_t b) { bits += s->lit[b] & 31u; }
+    __device__ __forceinline__ void match(uint32_t L, uint32_t d)
+    {
+        uint32_t sym, eb, ev;
+        gtz_dist_symbol(d, &sym, &eb, &ev);
+        bits += (s->len[L - 3u] & 31u) + (s->dist[sym] & 31u) + eb;
+    }
+};
+
+struct GtzHist {
+    GtzShared* s;
+    __device__ __forceinline__ void lit(uint32_t b) { atomicAdd(&s->hist[b], 1u); }
+    __device__ __forceinline__ void match(uint32_t L, uint32_t d)
+    {
+        uint32_t sym, eb, ev;
+        gtz_dist_symbol(d, &sym, &eb, &ev);
+        atomicAdd(&s->hist[gtz_len_symbol(L)], 1u);
+        atomicAdd(&s->hist[GTZ_DIST0 + sym], 1u);
+    }
+};
+
+struct GtzEmit {
+    GtzShared* s;
+    uint64_t acc;
+    uint32_t nacc, word;
+    __device__ __forceinline__ void put(uint32_t v, uint32_t n)
+    {
+        acc |= (uint64_t)v << nacc;
+        nacc += n;
+        if (nacc >= 32u) {
+            atomicOr(&s->tabs[word], (uint32_t)acc);
+            ++word;
+            acc >>= 32;
+            nacc -= 32u;
+        }
+    }
+    __device__ __forceinline__ void entry(uint32_t e) { put(e >> 5, e & 31u); }
+    __device__ __forceinline__ void lit(uint32_t b) { entry(s->lit[b]); }
+    __device__ __forceinline__ void match(uint32_t L, uint32_t d)
+    {
+        uint32_t sym, eb, ev;
+        gtz_dist_symbol(d, &sym, &eb, &ev);
+        entry(s->len[L - 3u]);
+        entry(s->dist[sym]);
+        if (eb) put(ev, eb);
+    }
+    __device__ __forceinline__ void flush()
+    {
+        if (nacc) atomicOr(&s->tabs[word], (uint32_t)acc);
+    }
+};
+
+// bytes [p2, p1] precede the current position; run of them are pending as a distance-4 match
+template <class Sink>
+__device__ __forceinline__ void gtz_flush_run(uint32_t run, uint32_t p2, uint32_t p1, Sink& sink)
+{
+    if (run >= 3u) sink.match(run, 4u);
+    else if (run == 2u) { sink.lit(p2); sink.lit(p1); }
+    else if (run == 1u) sink.lit(p1);
+}
+
+// One chunk: cells [k0, k1) of row i.  SEARCH: look for LZ77 matches and record them in farlist;
+// otherwise replay the recorded ones.  Returns nothing; tokens go to sink.
+template <bool SEARCH, class Sink>
+__device__ __forceinline__ void gtz_walk_chunk(GtzShared* s, uint32_t i, uint32_t k0, uint32_t k1, uint32_t* farlist, Sink& sink)
+{
+    const uint32_t kb = s->kb[i];
+    const uint32_t gbase = 16u * s->gw[i] - 16u * s->kw0[i]; // g = gbase + k
+    const int32_t cs = s->cs[i];
+    uint32_t run = 0, p2 = 0, p1 = 0, nfar = 0;
+    uint32_t k = k0;
+    uint32_t next_far = SEARCH ? 0u : farlist[0];
+    while (k < k1) {
+        const uint32_t g = gbase + k;
+        const uint32_t cw = s->cells[g >> 4];
+        const uint32_t code = (cw >> (2u * (g & 15u))) & 3u;
+        const bool has_prev = k > kb;
+        uint32_t x = 3u;
+        if (has_prev) {
+            const uint32_t gp = g - 1u;
+            x = code ^ ((s->cells[gp >> 4] >> (2u * (gp & 15u))) & 3u);
+        }
+        uint32_t f = 0, dbytes = 0;
+        if (SEARCH) {
+            if (x != 0u && k + GTZ_KEY_CELLS <= k1 && nfar < GTZ_MAX_FAR) {
+                const uint32_t key = gtz_window(s->cells, g) & (GTZ_KEYS - 1u);
+                const uint32_t q = min(g >> GTZ_SEG_SHIFT, GTZ_SEGS - 1u);
+                uint32_t cand[2];
+                cand[0] = s->tabs[(2u * q) * GTZ_KEYS + key];
+                cand[1] = q ? s->tabs[(2u * (q - 1u) + 1u) * GTZ_KEYS + key] - 1u : 0xFFFFFFFFu;
+                const int32_t my_byte = cs + 4 * (int32_t)k;
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    const uint32_t sg = cand[c];
+                    if (sg >= g) continue; // empty slot (0xFFFFFFFF) or not earlier than this cell
+                    uint32_t j = i;
+                    while (16u * s->gw[j] > sg) --j;
+                    const uint32_t ks = sg - 16u * s->gw[j] + 16u * s->kw0[j];
+                    const int32_t d = my_byte - (s->cs[j] + 4 * (int32_t)ks);
+                    if (d > 32768) continue;
+                    const uint32_t lim = min(k1 - k, s->ke[j] - ks);
+                    uint32_t n = 0;
+                    while (n < lim) {
+                        const uint32_t xw = gtz_window(s->cells, g + n) ^ gtz_window(s->cells, sg + n);
+                        if (xw) { n += (uint32_t)__builtin_ctz(xw) >> 1; break; }
+                        n += 16u;
+                    }
+                    n = min(n, lim);
+                    if (n > f || (n == f && (uint32_t)d < dbytes)) { f = n; dbytes = (uint32_t)d; }
+                }
+                if (f >= GTZ_KEY_CELLS) {
+                    // literal bytes the match replaces: alleles that differ from the cell before
+                    uint32_t breaks = 0;
+                    for (uint32_t o = 0; o < f; o += 16u) {
+                        const uint32_t cur = gtz_window(s->cells, g + o);
+                        uint32_t xw = (o == 0u && !has_prev) ? ((cur ^ (cur << 2)) | 3u) : (cur ^ gtz_window(s->cells, g + o - 1u));
+                        if (f - o < 16u) xw &= (1u << (2u * (f - o))) - 1u;
+                        breaks += (uint32_t)__builtin_popcount(xw);
+                    }
+                    if (breaks < GTZ_MIN_BREAKS) f = 0;
+                } else f = 0;
+                if (f) farlist[nfar] = (k - k0) | (f << 6) | (dbytes << 13);
+            }
+        } else if (nfar < GTZ_MAX_FAR && (next_far & 63u) == k - k0 && (next_far >> 6)) {
+            f = (next_far >> 6) & 127u;
+            dbytes = next_far >> 13;
+        }
+        if (f) {
+            gtz_flush_run(run, p2, p1, sink);
+            run = 0;
+            sink.match(4u * f, dbytes);
+            ++nfar;
+            if (!SEARCH) next_far = nfar < GTZ_MAX_FAR ? farlist[nfar] : 0u;
+            k += f;
+            const uint32_t gl = gbase + k - 1u; // the match's last cell precedes the next position
+            p2 = '0' + (((s->cells[gl >> 4] >> (2u * (gl & 15u))) >> 1) & 1u);
+            p1 = '\t';
+            continue;
+        }
+        const uint32_t a = '0' + (code & 1u), b = '0' + (code >> 1);
+        if (run > 254u) { sink.match(run, 4u); run = 0; } // keep a match within deflate's 258 bytes
+        if (x == 0u) { // the whole cell repeats its predecessor
+            run += 4u;
+        } else if (!has_prev) {
+            gtz_flush_run(run, p2, p1, sink);
+            run = 0;
+            sink.lit(a); sink.lit('/'); sink.lit(b); sink.lit('\t');
+        } else {
+            if (x & 1u) { gtz_flush_run(run, p2, p1, sink); sink.lit(a); run = 0; }
+            else ++run;
+            ++run; // '/'
+            if (x & 2u) { gtz_flush_run(run, a, '/', sink); sink.lit(b); run = 0; }
+            else ++run;
+            ++run; // '\t'
+        }
+        p2 = b;
+        p1 = '\t';
+        ++k;
+    }
+    gtz_flush_run(run, p2, p1, sink);
+    if (SEARCH && nfar < GTZ_MAX_FAR) farlist[nfar] = 0; // terminator: a recorded match has cells != 0
+}
+
+// byte of the virtual text at member offset pos, looked up from row i downwards
+__device__ __forceinline__ uint32_t gtz_text_byte(const GtzParams& p, const GtzShared* s, uint32_t m_row, uint32_t i, int32_t pos)
+{
+    uint32_t j = min(i, s->nr - 1u);
+    while (s->off[j] > pos) --j;
+    const int32_t c = pos - s->cs[j];
+    if (c < 0) return p.prefix[s->prefix_off[j] + (uint32_t)(pos - s->off[j])];
+    const uint32_t k = (uint32_t)c >> 2, which = (uint32_t)c & 3u;
+    if (which == 1u) return '/';
+    if (which == 3u) return k == p.S - 1u ? '\n' : '\t';
+    const uint32_t w = p.packed[(uint64_t)(m_row + j) * p.W + (k >> 4)];
+    const uint32_t code = (w >> (2u * (k & 15u))) & 3u;
+    return '0' + (which == 0u ? (code & 1u) : (code >> 1));
+}
+
+template <bool HIST>
+__global__ __launch_bounds__(GTZ_THREADS) void gtz_encode(const GtzParams p)
+{
+    __shared__ GtzShared sh;
+    GtzShared* s = &sh;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t m = HIST ? blockIdx.x * p.sample_step : blockIdx.x;
+    if (m >= p.n_blocks) return;
+    const uint32_t N = (uint32_t)min((uint64_t)BGZF_IN, p.n_bytes - (uint64_t)m * BGZF_IN);
+    const uint32_t m_row = p.member_row[m]; // relative to row_begin
+    const uint64_t B = p.text_base + (uint64_t)m * BGZF_IN;
+
+    // ---- rows that overlap the member ----
+    if (tid <= GTZ_MAX_ROWS) {
+        const uint64_t r = (uint64_t)m_row + tid;
+        int32_t off = 0x7FFFFFFF;
+        if (r < p.n_rows) {
+            const RowRec rec = p.recs[p.row_begin + r];
+            const int64_t rel = (int64_t)(rec.text_off - B);
+            if (rel < (int64_t)N) {
+                off = (int32_t)rel;
+                s->cs[tid] = off + (int32_t)rec.prefix_len;
+                s->prefix_off[tid] = rec.prefix_off;
+                s->cls[tid] = rec.cls;
+                s->nall[tid] = rec.n_alleles;
+                s->thr0[tid] = rec.thr[0];
+            }
+        }
+        s->off[tid] = off;
+    }
+    if (HIST)
+        for (uint32_t t = tid; t < GTZ_NSYM; t += GTZ_THREADS) s->hist[t] = 0;
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t nr = 0, ok = 1;
+        while (nr <= GTZ_MAX_ROWS && s->off[nr] != 0x7FFFFFFF) ++nr;
+        if (nr > GTZ_MAX_ROWS || p.S < 2u) ok = 0;
+        uint32_t items = 0, chunks = 0, words = 0, best_cells = 0, best_row = 0;
+        int32_t prev_end = 0;
+        for (uint32_t i = 0; i < nr && ok; ++i) {
+            if (s->cls[i] != 0u || s->nall[i] > 2u) { ok = 0; break; }
+            const int32_t cs = s->cs[i];
+            uint32_t kb = cs >= 0 ? 0u : ((uint32_t)(-cs) + 3u) >> 2;
+            uint32_t ke = (int32_t)N > cs ? (uint32_t)((int32_t)N - cs) >> 2 : 0u;
+            ke = min(ke, p.S - 1u);
+            if (ke < kb) ke = kb;
+            s->kb[i] = kb;
+            s->ke[i] = ke;
+            const bool any = ke > kb;
+            const uint32_t nch = any ? ((ke - 1u) >> 6) - (kb >> 6) + 1u : 0u;
+            const uint32_t nw = any ? ((ke - 1u) >> 4) - (kb >> 4) + 1u : 0u;
+            s->kw0[i] = kb >> 4;
+            s->gw[i] = words;
+            s->item_base[i] = items;
+            s->chunk_base[i] = chunks;
+            s->span_lo[i] = prev_end;
+            s->span_hi[i] = any ? cs + 4 * (int32_t)kb : prev_end;
+            if (any) prev_end = cs + 4 * (int32_t)ke;
+            items += 1u + nch;
+            chunks += nch;
+            words += nw + 1u;
+            if (ke - kb > best_cells) { best_cells = ke - kb; best_row = i; }
+        }
+        s->gw[nr] = words;
+        s->item_base[nr] = items; // the closing span
+        s->chunk_base[nr] = chunks;
+        s->span_lo[nr] = prev_end;
+        s->span_hi[nr] = (int32_t)N;
+        items += 1u;
+        if (items > GTZ_MAX_ITEMS || chunks > GTZ_MAX_CHUNKS || words + 1u > GTZ_CELL_WORDS) ok = 0;
+        s->nr = nr;
+        s->n_items = items;
+        s->ok = ok;
+        // table class from the alternative-allele frequency of the row that fills most of the member
+        const float q = 1.0f - ((float)s->thr0[best_row] + 1.0f) * (1.0f / 4294967296.0f);
+        s->klass = q < 0.02f ? 0u : q < 0.04f ? 1u : q < 0.08f ? 2u : q < 0.13f ? 3u : q < 0.2f ? 4u : q < 0.3f ? 5u : q < 0.4f ? 6u : 7u;
+    }
+    __syncthreads();
+    if (!s->ok) {
+        if (!HIST && tid == 0) p.fast[m] = 0;
+        return;
+    }
+    const uint32_t nr = s->nr, n_items = s->n_items, klass = s->klass;
+    const GtzClassTables* ct = &p.tables->cls[klass];
+
+    // ---- g space, key tables, code tables ----
+    for (uint32_t i = 0; i < nr; ++i) {
+        const uint32_t nw = s->gw[i + 1] - s->gw[i];
+        const uint32_t* src = p.packed + (uint64_t)(m_row + i) * p.W;
+        for (uint32_t w = tid; w < nw; w += GTZ_THREADS) {
+            const uint32_t kw = s->kw0[i] + w;
+            s->cells[s->gw[i] + w] = kw < p.W ? src[kw] : 0u;
+        }
+    }
+    if (tid == 0) s->cells[s->gw[nr]] = 0;
+    for (uint32_t t = tid; t < 2 * GTZ_SEGS * GTZ_KEYS; t += GTZ_THREADS) s->tabs[t] = ((t / GTZ_KEYS) & 1u) ? 0u : 0xFFFFFFFFu;
+    if (!HIST) {
+        s->lit[tid] = ct->lit[tid];
+        s->len[tid] = ct->len[tid];
+        if (tid < 32) s->dist[tid] = ct->dist[tid];
+        s->crc_table[tid] = p.tables->crc_table[tid];
+        if (tid <= GTZ_CHUNK_CELLS) s->crc_base[tid] = p.tables->crc_base[tid];
+        if (tid < GTZ_CHUNK_CELLS) { s->crc_unit_a[tid] = p.tables->crc_unit_a[tid]; s->crc_unit_b[tid] = p.tables->crc_unit_b[tid]; }
+    }
+    __syncthreads();
+    for (uint32_t i = 0; i < nr; ++i) {
+        const uint32_t kb = s->kb[i], ke = s->ke[i];
+        if (ke - kb < GTZ_KEY_CELLS) continue;
+        const uint32_t gbase = 16u * s->gw[i] - 16u * s->kw0[i];
+        for (uint32_t k = kb + tid; k + GTZ_KEY_CELLS <= ke; k += GTZ_THREADS) {
+            const uint32_t g = gbase + k;
+            const uint32_t key = gtz_window(s->cells, g) & (GTZ_KEYS - 1u);
+            const uint32_t q = min(g >> GTZ_SEG_SHIFT, GTZ_SEGS - 1u);
+            atomicMin(&s->tabs[(2u * q) * GTZ_KEYS + key], g);
+            atomicMax(&s->tabs[(2u * q + 1u) * GTZ_KEYS + key], g + 1u);
+        }
+    }
+    __syncthreads();
+
+    // ---- pass 1: tokenise, count bits (or symbols), CRC ----
+    uint32_t bits[2] = {0, 0}, part = 0;
+    uint32_t it_row[2], it_k0[2], it_k1[2];
+    for (int u = 0; u < 2; ++u) {
+        const uint32_t it = tid + (uint32_t)u * GTZ_THREADS;
+        it_row[u] = 0xFFFFFFFFu;
+        it_k0[u] = it_k1[u] = 0;
+        if (it >= n_items) continue;
+        uint32_t i = 0;
+        while (i < nr && s->item_base[i + 1] <= it) ++i; // row (or nr: the closing span)
+        it_row[u] = i;
+        const uint32_t local = it - s->item_base[i];
+        uint32_t crc = 0, nbytes = 0;
+        int32_t end_byte = 0;
+        if (local == 0u) {
+            // literal span: bytes between two rows' cell regions
+            const int32_t lo = s->span_lo[i], hi = s->span_hi[i];
+            it_k0[u] = 0xFFFFFFFFu;
+            uint32_t c = 0xFFFFFFFFu;
+            GtzCount cnt{s, 0};
+            GtzHist hs{s};
+            for (int32_t pos = lo; pos < hi; ++pos) {
+                const uint32_t b = gtz_text_byte(p, s, m_row, i, pos);
+                if (HIST) hs.lit(b);
+                else { cnt.lit(b); c = s->crc_table[(c ^ b) & 0xFFu] ^ (c >> 8); }
+            }
+            bits[u] = cnt.bits;
+            crc = ~c;
+            nbytes = (uint32_t)(hi - lo);
+            end_byte = hi;
+        } else {
+            const uint32_t kb = s->kb[i], ke = s->ke[i];
+            const uint32_t c64 = (kb >> 6) + local - 1u;
+            const uint32_t k0 = max(kb, 64u * c64), k1 = min(ke, 64u * c64 + 64u);
+            it_k0[u] = k0;
+            it_k1[u] = k1;
+            uint32_t* farlist = s->far + (s->chunk_base[i] + local - 1u) * GTZ_MAX_FAR;
+            if (HIST) {
+                GtzHist hs{s};
+                gtz_walk_chunk<true>(s, i, k0, k1, farlist, hs);
+            } else {
+                GtzCount cnt{s, 0};
+                gtz_walk_chunk<true>(s, i, k0, k1, farlist, cnt);
+                bits[u] = cnt.bits;
+                // CRC of the chunk's 4 (k1 - k0) bytes from its cells: base pattern + one unit per '1'
+                const uint32_t n = k1 - k0;
+                const uint32_t gbase = 16u * s->gw[i] - 16u * s->kw0[i];
+                uint32_t c = s->crc_base[n];
+                for (uint32_t e = 0; e < n; e += 16u) {
+                    // cells k1-1-e .. k1-16-e, i.e. the window that ends at cell k1-e
+                    const uint32_t cnt16 = min(16u, n - e);
+                    const uint32_t w = gtz_window(s->cells, gbase + k1 - e - cnt16);
+                    for (uint32_t t = 0; t < cnt16; ++t) {
+                        const uint32_t code = (w >> (2u * (cnt16 - 1u - t))) & 3u;
+                        if (code & 1u) c ^= s->crc_unit_a[e + t];
+                        if (code & 2u) c ^= s->crc_unit_b[e + t];
+                    }
+                }
+                crc = c;
+                nbytes = 4u * n;
+                end_byte = s->cs[i] + 4 * (int32_t)k1;
+            }
+        }
+        if (!HIST && nbytes) {
+            const uint32_t after = N - (uint32_t)end_byte;
+            const uint32_t q = after >> 6, r = after & 63u;
+            uint32_t shift = p.tables->crc_shift_chunk[q];
+            if (r) shift = crc_mulmod(shift, p.tables->crc_shift_byte[r]);
+            part ^= after ? crc_mulmod(shift, crc) : crc;
+        }
+    }
+    if (HIST) {
+        __syncthreads();
+        for (uint32_t t = tid; t < GTZ_NSYM; t += GTZ_THREADS)
+            if (s->hist[t]) atomicAdd(&p.hist[klass * GTZ_NSYM + t], s->hist[t]);
+        if (tid == 0) atomicAdd(&p.hist[klass * GTZ_NSYM + 256u], 1u); // end of block
+        return;
+    }
+
+    // ---- offsets: exclusive scan of the items' bit counts (items tid, then items 256 + tid) ----
+    const uint32_t lane = tid & 63u, wave = tid >> 6;
+    uint32_t incl0 = bits[0], incl1 = bits[1];
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t n0 = __shfl_up(incl0, d, 64), n1 = __shfl_up(incl1, d, 64);
+        if ((int)lane >= d) { incl0 += n0; incl1 += n1; }
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) part ^= __shfl_xor(part, d, 64);
+    if (lane == 63u) { s->scratch[wave] = incl0; s->scratch[GTZ_WAVES + wave] = incl1; }
+    if (lane == 0u) s->scratch[2 * GTZ_WAVES + wave] = part;
+    __syncthreads(); // also: every search is done, the key tables are free
+    uint32_t base0 = 0, base1 = 0, tot0 = 0, tot1 = 0, member_crc = 0;
+    for (uint32_t w = 0; w < GTZ_WAVES; ++w) {
+        const uint32_t a = s->scratch[w], b = s->scratch[GTZ_WAVES + w];
+        if (w < wave) { base0 += a; base1 += b; }
+        tot0 += a;
+        tot1 += b;
+        member_crc ^= s->scratch[2 * GTZ_WAVES + w];
+    }
+    const uint32_t hdr_bits = ct->hdr_nbits;
+    const uint32_t total = tot0 + tot1;
+    const uint32_t body_bits = hdr_bits + total + (ct->eob & 31u);
+    const uint32_t body = (body_bits + 7u) >> 3;
+    const uint32_t size = body + BGZF_MEMBER_OVERHEAD;
+    if (size > GTZ_STRIDE || body >= N + 5u) { // does not fit the slot, or a stored block would be smaller
+        if (tid == 0) p.fast[m] = 0;
+        return;
+    }
+
+    // ---- pass 2: the member image in LDS ----
+    const uint32_t image_words = (size + 3u) >> 2;
+    for (uint32_t t = tid; t < image_words; t += GTZ_THREADS) s->tabs[t] = 0;
+    __syncthreads();
+    if (tid < 18) {
+        const uint8_t h[18] = {0x1F, 0x8B, 8, 4, 0, 0, 0, 0, 0, 0xFF, 6, 0, 0x42, 0x43, 2, 0,
+                               (uint8_t)((size - 1u) & 0xFFu), (uint8_t)((size - 1u) >> 8)};
+        atomicOr(&s->tabs[tid >> 2], (uint32_t)h[tid] << (8u * (tid & 3u)));
+    }
+    if (tid < 8) {
+        const uint32_t v = tid < 4 ? member_crc : N;
+        const uint32_t at = 18u + body + tid;
+        atomicOr(&s->tabs[at >> 2], ((v >> (8u * (tid & 3u))) & 0xFFu) << (8u * (at & 3u)));
+    }
+    constexpr uint32_t BIT0 = 18u * 8u; // deflate bits start behind the gzip header
+    if (tid < (hdr_bits + 31u) / 32u) {
+        const uint32_t v = ct->hdr[tid];
+        atomicOr(&s->tabs[(BIT0 >> 5) + tid], v << (BIT0 & 31u));
+        atomicOr(&s->tabs[(BIT0 >> 5) + tid + 1u], v >> (32u - (BIT0 & 31u)));
+    }
+    for (int u = 0; u < 2; ++u) {
+        const uint32_t i = it_row[u];
+        if (i == 0xFFFFFFFFu) continue;
+        const uint32_t start = BIT0 + hdr_bits + (u == 0 ? base0 + incl0 - bits[0] : tot0 + base1 + incl1 - bits[1]);
+        GtzEmit e{s, 0, start & 31u, start >> 5};
+        if (it_k0[u] == 0xFFFFFFFFu) {
+            for (int32_t pos = s->span_lo[i]; pos < s->span_hi[i]; ++pos) e.lit(gtz_text_byte(p, s, m_row, i, pos));
+        } else {
+            const uint32_t it = tid + (uint32_t)u * GTZ_THREADS;
+            const uint32_t local = it - s->item_base[i];
+            uint32_t* farlist = s->far + (s->chunk_base[i] + local - 1u) * GTZ_MAX_FAR;
+            gtz_walk_chunk<false>(s, i, it_k0[u], it_k1[u], farlist, e);
+        }
+        e.flush();
+    }
+    if (tid == 0) {
+        const uint32_t start = BIT0 + hdr_bits + total;
+        GtzEmit e{s, 0, start & 31u, start >> 5};
+        e.entry(ct->eob);
+        e.flush();
+        p.sizes[m] = size;
+        p.fast[m] = 1;
+    }
+    __syncthreads();
+    uint4* dst = reinterpret_cast<uint4*>(p.stage + (uint64_t)m * GTZ_STRIDE);
+    const uint4* src = reinterpret_cast<const uint4*>(s->tabs);
+    for (uint32_t t = tid; t < (size + 15u) >> 4; t += GTZ_THREADS) dst[t] = src[t];
+}
+
+// staging slot -> the member's place in the stream (offsets from bgzf_scan)
+__global__ __launch_bounds__(256) void gtz_compact(const GtzParams p)
+{
+    const uint32_t m = blockIdx.x;
+    if (!p.fast[m]) return;
+    const uint32_t size = p.sizes[m] & 0x3FFFFFFFu;
+    const uint8_t* src = p.stage + (uint64_t)m * GTZ_STRIDE;
+    uint8_t* dst = p.out + p.offsets[m];
+    const uint32_t n16 = size >> 4;
+    for (uint32_t t = threadIdx.x; t < n16; t += 256u) {
+        const uint4 v = reinterpret_cast<const uint4*>(src)[t];
+        __builtin_memcpy(dst + 16u * t, &v, 16);
+    }
+    for (uint32_t t = 16u * n16 + threadIdx.x; t < size; t += 256u) dst[t] = src[t];
+}
+
+} // namespace dnaf

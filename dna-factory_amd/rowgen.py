@@ -99,15 +99,16 @@ class RowGenerator:
         p = self.ctx.read_packed(n_rows, self.words_per_row) if packed else None
         return t, off, p
 
-    def generate_bgzf(self, row_begin=0, n_rows=None, reuse_tables=False):
+    def generate_bgzf(self, row_begin=0, n_rows=None, reuse_tables=False, text_domain=False):
         """Rows [row_begin, row_begin+n_rows) as BGZF members compressed on the GPU (no EOF block): only the
-        compressed bytes cross PCIe.  Returns (bgzf u8[], uncompressed text bytes)."""
+        compressed bytes cross PCIe.  Returns (bgzf u8[], uncompressed text bytes).  text_domain=True keeps the
+        genotype-domain encoder out (every member is made from the text)."""
         if self.n_rows is None:
             raise capi.DnafError(capi.ERR_STATE, "set_snps must be called before generate")
         if n_rows is None:
             n_rows = self.n_rows - row_begin
-        self.ctx.generate(row_begin, n_rows, capi.OUT_TEXT)
-        n = self.ctx.bgzf_compress(reuse_tables=reuse_tables)
+        self.ctx.generate(row_begin, n_rows, capi.OUT_TEXT | (0 if text_domain else capi.OUT_PACKED))
+        n = self.ctx.bgzf_compress(reuse_tables=reuse_tables, text_domain=text_domain)
         return self.ctx.read_bgzf(n), self.ctx.text_bytes(row_begin, n_rows)
 
     def lines(self, row_begin=0, n_rows=None):

@@ -159,6 +159,7 @@ int dnaf_device_buffers(dnaf_ctx* ctx, void** d_text, uint64_t* text_bytes, void
  * block) in device memory; any gzip reader returns the input bytes.  flags: DNAF_BGZF_REUSE_TABLES
  * keeps the Huffman tables of the previous call instead of sampling the new text.  Synchronises. */
 #define DNAF_BGZF_REUSE_TABLES 1u
+#define DNAF_BGZF_TEXT_DOMAIN 2u /* encode every member from the text (no genotype-domain members) */
 int dnaf_bgzf_compress(dnaf_ctx* ctx, uint32_t flags, uint64_t* n_bytes);
 int dnaf_read_bgzf(dnaf_ctx* ctx, void* dst, uint64_t dst_cap, uint64_t* n_bytes);
 /* The same data through the context's pinned staging buffer (DMA at PCIe rate instead of a pageable
