@@ -48,6 +48,7 @@ struct BgzfParams {
     const uint64_t* offsets; // [n_blocks+1] exclusive scan of sizes
     uint8_t* out;
     const uint8_t* fast;     // [n_blocks] or null: 1 = the genotype-domain encoder (gtz_kernels.hip.h) made this member
+    const uint32_t* todo;    // null: every block; else [0] = count, [1..] = the blocks bgzf_size / bgzf_encode<SMALL> are launched over
 };
 
 __device__ __forceinline__ uint32_t block_len(const BgzfParams& p, uint32_t b)
@@ -268,7 +269,7 @@ __global__ __launch_bounds__(BGZF_THREADS) void bgzf_size(const BgzfParams p)
     __shared__ uint32_t tab[512];
     __shared__ uint32_t crc_tab[4][256];
     __shared__ uint32_t scratch[BGZF_WAVES];
-    const uint32_t b = blockIdx.x, tid = threadIdx.x;
+    const uint32_t b = p.todo ? p.todo[1u + blockIdx.x] : blockIdx.x, tid = threadIdx.x;
     if (p.fast && p.fast[b]) return;
     load_code_table(p, tab);
     crc_tab[tid >> 8][tid & 255u] = p.tables->crc_table[tid >> 8][tid & 255u];
@@ -345,6 +346,27 @@ __global__ __launch_bounds__(1024) void bgzf_scan(const uint32_t* sizes, uint32_
     }
 }
 
+// the blocks with flag[b] == 0, in order: list[0] = how many, list[1..] = which (one workgroup)
+__global__ __launch_bounds__(1024) void bgzf_list_unset(const uint8_t* flag, uint32_t n, uint32_t* list)
+{
+    __shared__ uint32_t part[1024];
+    const uint32_t per = (n + 1023u) / 1024u;
+    const uint32_t lo = min(n, threadIdx.x * per), hi = min(n, lo + per);
+    uint32_t cnt = 0;
+    for (uint32_t i = lo; i < hi; ++i) cnt += flag[i] ? 0u : 1u;
+    part[threadIdx.x] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t run = 0;
+        for (uint32_t i = 0; i < 1024; ++i) { const uint32_t t = part[i]; part[i] = run; run += t; }
+        list[0] = run;
+    }
+    __syncthreads();
+    uint32_t at = part[threadIdx.x];
+    for (uint32_t i = lo; i < hi; ++i)
+        if (!flag[i]) list[1u + at++] = i;
+}
+
 // OUT_BYTES = BGZF_OUT_SMALL: every member whose body fits 8 KB, and the stored ones (LDS < 80 KB: two
 // workgroups per CU).  OUT_BYTES = BGZF_OUT_LARGE: the rest.  Both are launched over all blocks; a
 // workgroup whose block belongs to the other kernel exits at once.
@@ -356,7 +378,7 @@ __global__ __launch_bounds__(BGZF_THREADS, OUT_BYTES == BGZF_OUT_SMALL ? 8 : 4) 
     __shared__ uint32_t tab[512];
     __shared__ uint32_t scratch[BGZF_WAVES];
     const uint32_t tid = threadIdx.x;
-    const uint32_t b = OUT_BYTES == BGZF_OUT_LARGE ? p.large_list[1u + blockIdx.x] : blockIdx.x;
+    const uint32_t b = OUT_BYTES == BGZF_OUT_LARGE ? p.large_list[1u + blockIdx.x] : p.todo ? p.todo[1u + blockIdx.x] : blockIdx.x;
     if (p.fast && p.fast[b]) return;
     const uint32_t N = block_len(p, b);
     const uint8_t* blk = p.text + (uint64_t)b * BGZF_IN;

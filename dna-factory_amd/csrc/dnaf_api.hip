@@ -102,6 +102,7 @@ struct dnaf_ctx {
     uint32_t* d_gtz_hist = nullptr;
     uint32_t* d_member_row = nullptr;
     uint8_t* d_fast = nullptr;
+    uint32_t* d_todo = nullptr;
     uint8_t* d_stage = nullptr;
     uint64_t stage_cap = 0;
     bool have_gtz_tables = false;
@@ -218,6 +219,7 @@ int dnaf_destroy(dnaf_ctx* c)
     dev_free(c->d_gtz_hist);
     dev_free(c->d_member_row);
     dev_free(c->d_fast);
+    dev_free(c->d_todo);
     dev_free(c->d_stage);
     for (hipEvent_t e : c->zev) if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : c->evs) (void)hipEventDestroy(e);
@@ -853,7 +855,9 @@ int dnaf_bgzf_compress(dnaf_ctx* c, uint32_t flags, uint64_t* n_bytes)
         dev_free(c->d_offsets);
         dev_free(c->d_member_row);
         dev_free(c->d_fast);
+        dev_free(c->d_todo);
         c->blocks_cap = 0;
+        HIP_TRY(c, hipMalloc((void**)&c->d_todo, ((uint64_t)nb + 1) * sizeof(uint32_t)));
         HIP_TRY(c, hipMalloc((void**)&c->d_member_row, (uint64_t)nb * sizeof(uint32_t)));
         HIP_TRY(c, hipMalloc((void**)&c->d_fast, (uint64_t)nb));
         HIP_TRY(c, hipMalloc((void**)&c->d_crcs, (uint64_t)nb * sizeof(uint32_t)));
@@ -877,6 +881,8 @@ int dnaf_bgzf_compress(dnaf_ctx* c, uint32_t flags, uint64_t* n_bytes)
     p.offsets = c->d_offsets;
     p.out = nullptr;
     p.fast = gtz ? c->d_fast : nullptr;
+    p.todo = nullptr;
+    uint32_t n_todo = nb; // members the text-domain kernels encode
     float ms_total = 0.f, ms = 0.f;
     dnaf::GtzParams g;
     if (gtz) {
@@ -926,7 +932,11 @@ int dnaf_bgzf_compress(dnaf_ctx* c, uint32_t flags, uint64_t* n_bytes)
         }
         hipLaunchKernelGGL((dnaf::gtz_encode<false>), dim3(nb), dim3(dnaf::GTZ_THREADS), 0, c->stream, g);
         HIP_TRY(c, hipGetLastError());
+        hipLaunchKernelGGL(dnaf::bgzf_list_unset, dim3(1), dim3(1024), 0, c->stream, (const uint8_t*)c->d_fast, nb, c->d_todo);
+        HIP_TRY(c, hipGetLastError());
         HIP_TRY(c, hipEventRecord(c->zev[1], c->stream));
+        HIP_TRY(c, hipMemcpyAsync(&n_todo, c->d_todo, sizeof n_todo, hipMemcpyDeviceToHost, c->stream));
+        p.todo = c->d_todo;
         HIP_TRY(c, hipStreamSynchronize(c->stream));
         HIP_TRY(c, hipEventElapsedTime(&ms, c->zev[0], c->zev[1]));
         ms_total += ms;
@@ -953,8 +963,10 @@ int dnaf_bgzf_compress(dnaf_ctx* c, uint32_t flags, uint64_t* n_bytes)
     // 2. exact member sizes, 3. their exclusive scan
     uint64_t total = 0;
     HIP_TRY(c, hipEventRecord(c->zev[0], c->stream));
-    hipLaunchKernelGGL(dnaf::bgzf_size, dim3(nb), dim3(dnaf::BGZF_THREADS), 0, c->stream, p);
-    HIP_TRY(c, hipGetLastError());
+    if (n_todo) {
+        hipLaunchKernelGGL(dnaf::bgzf_size, dim3(n_todo), dim3(dnaf::BGZF_THREADS), 0, c->stream, p);
+        HIP_TRY(c, hipGetLastError());
+    }
     uint32_t n_large = 0;
     hipLaunchKernelGGL(dnaf::bgzf_scan, dim3(1), dim3(1024), 0, c->stream, (const uint32_t*)c->d_sizes, nb, c->d_offsets, c->d_large);
     HIP_TRY(c, hipGetLastError());
@@ -974,8 +986,10 @@ int dnaf_bgzf_compress(dnaf_ctx* c, uint32_t flags, uint64_t* n_bytes)
     // 4. encode every member at its offset
     p.out = c->d_bgzf;
     HIP_TRY(c, hipEventRecord(c->zev[0], c->stream));
-    hipLaunchKernelGGL((dnaf::bgzf_encode<dnaf::BGZF_OUT_SMALL>), dim3(nb), dim3(dnaf::BGZF_THREADS), 0, c->stream, p);
-    HIP_TRY(c, hipGetLastError());
+    if (n_todo) {
+        hipLaunchKernelGGL((dnaf::bgzf_encode<dnaf::BGZF_OUT_SMALL>), dim3(n_todo), dim3(dnaf::BGZF_THREADS), 0, c->stream, p);
+        HIP_TRY(c, hipGetLastError());
+    }
     if (n_large) {
         hipLaunchKernelGGL((dnaf::bgzf_encode<dnaf::BGZF_OUT_LARGE>), dim3(n_large), dim3(dnaf::BGZF_THREADS), 0, c->stream, p);
         HIP_TRY(c, hipGetLastError());

@@ -33,6 +33,8 @@ struct GtzClassTables {
     uint32_t eob;
     uint32_t hdr_nbits;
     uint32_t hdr[GTZ_HDR_WORDS];
+    uint64_t len_nb[2];  // code length of length symbol 257 + n at nibble n (the bit-count pass works from registers)
+    uint64_t dist_nb[2]; // code length of distance symbol n at nibble n
 };
 
 struct GtzTables {
@@ -96,6 +98,9 @@ inline void gtz_build_class(const uint64_t* litlen_hist, const uint64_t* dist_hi
     }
     memset(t->dist, 0, sizeof t->dist);
     for (uint32_t s = 0; s < 30; ++s) t->dist[s] = (dc[s] << 5) | dl[s];
+    t->len_nb[0] = t->len_nb[1] = t->dist_nb[0] = t->dist_nb[1] = 0;
+    for (uint32_t s = 0; s < 29; ++s) t->len_nb[s >> 4] |= (uint64_t)ll[257 + s] << (4 * (s & 15));
+    for (uint32_t s = 0; s < 30; ++s) t->dist_nb[s >> 4] |= (uint64_t)dl[s] << (4 * (s & 15));
 
     // header: BFINAL=1, BTYPE=10, HLIT=286, HDIST=30, code lengths run-length coded with their own Huffman code
     std::vector<uint8_t> all(ll);

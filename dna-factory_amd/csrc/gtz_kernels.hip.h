@@ -9,12 +9,14 @@
 //      word-aligned per row), 960 words instead of 61 KB of text;
 //   2. every 5-cell key (10 bits) is entered into direct-indexed tables -- earliest and latest position
 //      per quarter of the member -- with LDS atomics;
-//   3. each thread tokenises one 64-cell chunk (256 text bytes): where a cell differs from its predecessor
-//      it looks the key up, extends the candidates by XOR / count-trailing-zeros on the 2-bit stream and
-//      takes an LZ77 match when that beats literals; everything else is coded like the text-domain
-//      encoder does (matches at distance 4, literals);  the gaps between rows' cell regions (last cell of
-//      a row, "\n", the next row's fixed columns) are literal spans;
-//   4. bit counts are scanned, the tokens are emitted into an LDS image of the whole member (gzip header,
+//   3. each thread owns one 64-cell chunk (256 text bytes), held in four registers.  Search: the lanes of
+//      a wave step together from one "break" (a cell that differs from its predecessor) to the next,
+//      look the key up, extend the candidates by XOR / count-trailing-zeros on the 2-bit stream and
+//      record an LZ77 match when it replaces enough literals.  Walk: the chunk becomes tokens -- the
+//      recorded matches, matches at distance 4 for repeating bytes, literals for the rest; the gaps
+//      between rows' cell regions (last cell of a row, "\n", the next row's fixed columns) are literal
+//      spans;
+//   4. bit counts are scanned, the walk is repeated into an LDS image of the whole member (gzip header,
 //      deflate block, CRC-32, ISIZE) and the image is written to the member's staging slot;  the member
 //      CRC comes from the cells by linearity of the CRC (per-cell unit tables), never from text bytes.
 //
@@ -37,10 +39,10 @@ constexpr uint32_t GTZ_KEY_CELLS = 5;
 constexpr uint32_t GTZ_KEYS = 1u << (2 * GTZ_KEY_CELLS);
 constexpr uint32_t GTZ_SEGS = 4;          // quarters of the member's g space (4096 cells each)
 constexpr uint32_t GTZ_SEG_SHIFT = 12;
-constexpr uint32_t GTZ_MAX_ROWS = 32;     // rows overlapping one member
-constexpr uint32_t GTZ_MAX_CHUNKS = 304;  // 240 + two partial chunks per row
+constexpr uint32_t GTZ_MAX_ROWS = 16;     // rows overlapping one member
+constexpr uint32_t GTZ_MAX_CHUNKS = 240 + 2 * GTZ_MAX_ROWS;
 constexpr uint32_t GTZ_MAX_ITEMS = 2 * GTZ_THREADS; // chunks + literal spans, two per thread
-constexpr uint32_t GTZ_MAX_FAR = 12;      // LZ77 matches per chunk (64 cells / 5)
+constexpr uint32_t GTZ_MAX_FAR = 10;      // LZ77 matches recorded per chunk
 constexpr uint32_t GTZ_CELL_WORDS = BGZF_IN / 64 + 2 * GTZ_MAX_ROWS + 8;
 constexpr uint32_t GTZ_STRIDE = 16384;    // staging slot of a member
 constexpr uint32_t GTZ_OUT_WORDS = GTZ_STRIDE / 4;
@@ -86,10 +88,9 @@ struct GtzShared {
     uint32_t tabs[2 * GTZ_SEGS * GTZ_KEYS]; // [seg][0 = earliest, 1 = latest + 1][key]; later the member image
     uint32_t cells[GTZ_CELL_WORDS + 4];
     uint32_t far[GTZ_MAX_CHUNKS * GTZ_MAX_FAR]; // cell in chunk | cells << 6 | distance in bytes << 13
-    uint32_t lit[256], len[256], dist[32];
+    uint32_t codes[256 + 256 + 32];             // lit, len, dist code tables; the symbol histogram in gtz_encode<true>
     uint32_t crc_table[256];
     uint32_t crc_base[GTZ_CHUNK_CELLS + 1], crc_unit_a[GTZ_CHUNK_CELLS], crc_unit_b[GTZ_CHUNK_CELLS];
-    uint32_t hist[GTZ_NSYM];
     // rows overlapping the member
     int32_t off[GTZ_MAX_ROWS + 2];     // row start relative to the member's first byte
     int32_t cs[GTZ_MAX_ROWS + 2];      // first cell's byte, relative to the member
@@ -102,9 +103,14 @@ struct GtzShared {
     int32_t span_lo[GTZ_MAX_ROWS + 2], span_hi[GTZ_MAX_ROWS + 2];
     uint32_t thr0[GTZ_MAX_ROWS + 2];
     uint8_t cls[GTZ_MAX_ROWS + 2], nall[GTZ_MAX_ROWS + 2];
-    uint32_t scratch[2 * GTZ_WAVES + 4];
+    uint32_t scratch[3 * GTZ_WAVES];
     uint32_t nr, n_items, ok, klass;
+    __device__ __forceinline__ uint32_t* lit() { return codes; }
+    __device__ __forceinline__ uint32_t* len() { return codes + 256; }
+    __device__ __forceinline__ uint32_t* dist() { return codes + 512; }
+    __device__ __forceinline__ uint32_t* hist() { return codes; }
 };
+static_assert(GTZ_NSYM <= 544, "the histogram reuses the code tables");
 
 // 16 cells of the 2-bit stream starting at g
 __device__ __forceinline__ uint32_t gtz_window(const uint32_t* cells, uint32_t g)
@@ -112,6 +118,62 @@ __device__ __forceinline__ uint32_t gtz_window(const uint32_t* cells, uint32_t g
     const uint32_t w = g >> 4;
     const uint64_t v = ((uint64_t)cells[w + 1] << 32) | cells[w];
     return (uint32_t)(v >> (2u * (g & 15u)));
+}
+
+// The 64 cells of a chunk (cell j at bits 2j of lo:hi) and their difference from the cell before.
+struct GtzChunk {
+    uint64_t lo, hi;   // cell codes
+    uint64_t xlo, xhi; // code ^ previous cell's code; 3 where there is no previous cell in the member
+    uint32_t j0, j1;   // cells [j0, j1) of the 64-cell grid belong to the item
+    bool head;         // cell j0 is the first cell of the row's region: nothing before it to refer to
+    __device__ __forceinline__ uint32_t code(uint32_t j) const { return (uint32_t)((j < 32u ? lo >> (2u * j) : hi >> (2u * j - 64u)) & 3u); }
+    __device__ __forceinline__ uint32_t x(uint32_t j) const { return (uint32_t)((j < 32u ? xlo >> (2u * j) : xhi >> (2u * j - 64u)) & 3u); }
+    // 16 cells from j (cells past the chunk read as 0)
+    __device__ __forceinline__ uint32_t window(uint32_t j) const
+    {
+        if (j >= 32u) return j >= 64u ? 0u : (uint32_t)(hi >> (2u * j - 64u));
+        uint64_t v = lo >> (2u * j);
+        if (j) v |= hi << (64u - 2u * j);
+        return (uint32_t)v;
+    }
+};
+
+__device__ __forceinline__ uint64_t gtz_low_mask(uint32_t nbits) { return nbits >= 64u ? ~0ull : (1ull << nbits) - 1ull; }
+
+// first cell >= pos whose break bit is set (64 if none); b has one bit per cell at even positions
+__device__ __forceinline__ uint32_t gtz_next_break(uint64_t blo, uint64_t bhi, uint32_t pos)
+{
+    if (pos < 32u) {
+        const uint64_t t = blo & ~gtz_low_mask(2u * pos);
+        if (t) return (uint32_t)__builtin_ctzll(t) >> 1;
+        return bhi ? 32u + ((uint32_t)__builtin_ctzll(bhi) >> 1) : 64u;
+    }
+    if (pos >= 64u) return 64u;
+    const uint64_t t = bhi & ~gtz_low_mask(2u * pos - 64u);
+    return t ? 32u + ((uint32_t)__builtin_ctzll(t) >> 1) : 64u;
+}
+
+__device__ __forceinline__ GtzChunk gtz_load_chunk(const GtzShared* s, uint32_t i, uint32_t c64, uint32_t k0, uint32_t k1)
+{
+    GtzChunk c;
+    const int32_t w0 = (int32_t)s->gw[i] + 4 * (int32_t)c64 - (int32_t)s->kw0[i]; // g-space word of cell 64 c64
+    const int32_t wlo = (int32_t)s->gw[i], whi = (int32_t)s->gw[i + 1];
+    uint32_t w[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) w[q] = (w0 + q >= wlo && w0 + q < whi) ? s->cells[w0 + q] : 0u;
+    const uint32_t prev = (w0 - 1 >= wlo) ? s->cells[w0 - 1] >> 30 : 0u;
+    c.lo = ((uint64_t)w[1] << 32) | w[0];
+    c.hi = ((uint64_t)w[3] << 32) | w[2];
+    c.j0 = k0 - 64u * c64;
+    c.j1 = k1 - 64u * c64;
+    c.xlo = c.lo ^ ((c.lo << 2) | prev);
+    c.xhi = c.hi ^ ((c.hi << 2) | (c.lo >> 62));
+    c.head = k0 == s->kb[i];
+    if (c.head) { // the region's first cell has no predecessor inside the member
+        if (c.j0 < 32u) c.xlo |= 3ull << (2u * c.j0);
+        else c.xhi |= 3ull << (2u * c.j0 - 64u);
+    }
+    return c;
 }
 
 __device__ __forceinline__ uint32_t gtz_len_symbol(uint32_t L)
@@ -135,26 +197,26 @@ __device__ __forceinline__ void gtz_dist_symbol(uint32_t d, uint32_t* sym, uint3
 }
 
 struct GtzCount {
-    const GtzShared* s;
+    GtzShared* s;
     uint32_t bits;
-    __device__ __forceinline__ void lit(uint32_t b) { bits += s->lit[b] & 31u; }
+    __device__ __forceinline__ void lit(uint32_t b) { bits += s->lit()[b] & 31u; }
     __device__ __forceinline__ void match(uint32_t L, uint32_t d)
     {
         uint32_t sym, eb, ev;
         gtz_dist_symbol(d, &sym, &eb, &ev);
-        bits += (s->len[L - 3u] & 31u) + (s->dist[sym] & 31u) + eb;
+        bits += (s->len()[L - 3u] & 31u) + (s->dist()[sym] & 31u) + eb;
     }
 };
 
 struct GtzHist {
     GtzShared* s;
-    __device__ __forceinline__ void lit(uint32_t b) { atomicAdd(&s->hist[b], 1u); }
+    __device__ __forceinline__ void lit(uint32_t b) { atomicAdd(&s->hist()[b], 1u); }
     __device__ __forceinline__ void match(uint32_t L, uint32_t d)
     {
         uint32_t sym, eb, ev;
         gtz_dist_symbol(d, &sym, &eb, &ev);
-        atomicAdd(&s->hist[gtz_len_symbol(L)], 1u);
-        atomicAdd(&s->hist[GTZ_DIST0 + sym], 1u);
+        atomicAdd(&s->hist()[gtz_len_symbol(L)], 1u);
+        atomicAdd(&s->hist()[GTZ_DIST0 + sym], 1u);
     }
 };
 
@@ -174,13 +236,13 @@ struct GtzEmit {
         }
     }
     __device__ __forceinline__ void entry(uint32_t e) { put(e >> 5, e & 31u); }
-    __device__ __forceinline__ void lit(uint32_t b) { entry(s->lit[b]); }
+    __device__ __forceinline__ void lit(uint32_t b) { entry(s->lit()[b]); }
     __device__ __forceinline__ void match(uint32_t L, uint32_t d)
     {
         uint32_t sym, eb, ev;
         gtz_dist_symbol(d, &sym, &eb, &ev);
-        entry(s->len[L - 3u]);
-        entry(s->dist[sym]);
+        entry(s->len()[L - 3u]);
+        entry(s->dist()[sym]);
         if (eb) put(ev, eb);
     }
     __device__ __forceinline__ void flush()
@@ -189,116 +251,9 @@ struct GtzEmit {
     }
 };
 
-// bytes [p2, p1] precede the current position; run of them are pending as a distance-4 match
-template <class Sink>
-__device__ __forceinline__ void gtz_flush_run(uint32_t run, uint32_t p2, uint32_t p1, Sink& sink)
-{
-    if (run >= 3u) sink.match(run, 4u);
-    else if (run == 2u) { sink.lit(p2); sink.lit(p1); }
-    else if (run == 1u) sink.lit(p1);
-}
-
-// One chunk: cells [k0, k1) of row i.  SEARCH: look for LZ77 matches and record them in farlist;
-// otherwise replay the recorded ones.  Returns nothing; tokens go to sink.
-template <bool SEARCH, class Sink>
-__device__ __forceinline__ void gtz_walk_chunk(GtzShared* s, uint32_t i, uint32_t k0, uint32_t k1, uint32_t* farlist, Sink& sink)
-{
-    const uint32_t kb = s->kb[i];
-    const uint32_t gbase = 16u * s->gw[i] - 16u * s->kw0[i]; // g = gbase + k
-    const int32_t cs = s->cs[i];
-    uint32_t run = 0, p2 = 0, p1 = 0, nfar = 0;
-    uint32_t k = k0;
-    uint32_t next_far = SEARCH ? 0u : farlist[0];
-    while (k < k1) {
-        const uint32_t g = gbase + k;
-        const uint32_t cw = s->cells[g >> 4];
-        const uint32_t code = (cw >> (2u * (g & 15u))) & 3u;
-        const bool has_prev = k > kb;
-        uint32_t x = 3u;
-        if (has_prev) {
-            const uint32_t gp = g - 1u;
-            x = code ^ ((s->cells[gp >> 4] >> (2u * (gp & 15u))) & 3u);
-        }
-        uint32_t f = 0, dbytes = 0;
-        if (SEARCH) {
-            if (x != 0u && k + GTZ_KEY_CELLS <= k1 && nfar < GTZ_MAX_FAR) {
-                const uint32_t key = gtz_window(s->cells, g) & (GTZ_KEYS - 1u);
-                const uint32_t q = min(g >> GTZ_SEG_SHIFT, GTZ_SEGS - 1u);
-                uint32_t cand[2];
-                cand[0] = s->tabs[(2u * q) * GTZ_KEYS + key];
-                cand[1] = q ? s->tabs[(2u * (q - 1u) + 1u) * GTZ_KEYS + key] - 1u : 0xFFFFFFFFu;
-                const int32_t my_byte = cs + 4 * (int32_t)k;
-#pragma unroll
-                for (int c = 0; c < 2; ++c) {
-                    const uint32_t sg = cand[c];
-                    if (sg >= g) continue; // empty slot (0xFFFFFFFF) or not earlier than this cell
-                    uint32_t j = i;
-                    while (16u * s->gw[j] > sg) --j;
-                    const uint32_t ks = sg - 16u * s->gw[j] + 16u * s->kw0[j];
-                    const int32_t d = my_byte - (s->cs[j] + 4 * (int32_t)ks);
-                    if (d > 32768) continue;
-                    const uint32_t lim = min(k1 - k, s->ke[j] - ks);
-                    uint32_t n = 0;
-                    while (n < lim) {
-                        const uint32_t xw = gtz_window(s->cells, g + n) ^ gtz_window(s->cells, sg + n);
-                        if (xw) { n += (uint32_t)__builtin_ctz(xw) >> 1; break; }
-                        n += 16u;
-                    }
-                    n = min(n, lim);
-                    if (n > f || (n == f && (uint32_t)d < dbytes)) { f = n; dbytes = (uint32_t)d; }
-                }
-                if (f >= GTZ_KEY_CELLS) {
-                    // literal bytes the match replaces: alleles that differ from the cell before
-                    uint32_t breaks = 0;
-                    for (uint32_t o = 0; o < f; o += 16u) {
-                        const uint32_t cur = gtz_window(s->cells, g + o);
-                        uint32_t xw = (o == 0u && !has_prev) ? ((cur ^ (cur << 2)) | 3u) : (cur ^ gtz_window(s->cells, g + o - 1u));
-                        if (f - o < 16u) xw &= (1u << (2u * (f - o))) - 1u;
-                        breaks += (uint32_t)__builtin_popcount(xw);
-                    }
-                    if (breaks < GTZ_MIN_BREAKS) f = 0;
-                } else f = 0;
-                if (f) farlist[nfar] = (k - k0) | (f << 6) | (dbytes << 13);
-            }
-        } else if (nfar < GTZ_MAX_FAR && (next_far & 63u) == k - k0 && (next_far >> 6)) {
-            f = (next_far >> 6) & 127u;
-            dbytes = next_far >> 13;
-        }
-        if (f) {
-            gtz_flush_run(run, p2, p1, sink);
-            run = 0;
-            sink.match(4u * f, dbytes);
-            ++nfar;
-            if (!SEARCH) next_far = nfar < GTZ_MAX_FAR ? farlist[nfar] : 0u;
-            k += f;
-            const uint32_t gl = gbase + k - 1u; // the match's last cell precedes the next position
-            p2 = '0' + (((s->cells[gl >> 4] >> (2u * (gl & 15u))) >> 1) & 1u);
-            p1 = '\t';
-            continue;
-        }
-        const uint32_t a = '0' + (code & 1u), b = '0' + (code >> 1);
-        if (run > 254u) { sink.match(run, 4u); run = 0; } // keep a match within deflate's 258 bytes
-        if (x == 0u) { // the whole cell repeats its predecessor
-            run += 4u;
-        } else if (!has_prev) {
-            gtz_flush_run(run, p2, p1, sink);
-            run = 0;
-            sink.lit(a); sink.lit('/'); sink.lit(b); sink.lit('\t');
-        } else {
-            if (x & 1u) { gtz_flush_run(run, p2, p1, sink); sink.lit(a); run = 0; }
-            else ++run;
-            ++run; // '/'
-            if (x & 2u) { gtz_flush_run(run, a, '/', sink); sink.lit(b); run = 0; }
-            else ++run;
-            ++run; // '\t'
-        }
-        p2 = b;
-        p1 = '\t';
-        ++k;
-    }
-    gtz_flush_run(run, p2, p1, sink);
-    if (SEARCH && nfar < GTZ_MAX_FAR) farlist[nfar] = 0; // terminator: a recorded match has cells != 0
-}
+} // namespace dnaf
+#include "gtz_tokens.hip.h"
+namespace dnaf {
 
 // byte of the virtual text at member offset pos, looked up from row i downwards
 __device__ __forceinline__ uint32_t gtz_text_byte(const GtzParams& p, const GtzShared* s, uint32_t m_row, uint32_t i, int32_t pos)
@@ -345,8 +300,6 @@ __global__ __launch_bounds__(GTZ_THREADS) void gtz_encode(const GtzParams p)
         }
         s->off[tid] = off;
     }
-    if (HIST)
-        for (uint32_t t = tid; t < GTZ_NSYM; t += GTZ_THREADS) s->hist[t] = 0;
     __syncthreads();
     if (tid == 0) {
         uint32_t nr = 0, ok = 1;
@@ -409,12 +362,14 @@ __global__ __launch_bounds__(GTZ_THREADS) void gtz_encode(const GtzParams p)
             s->cells[s->gw[i] + w] = kw < p.W ? src[kw] : 0u;
         }
     }
-    if (tid == 0) s->cells[s->gw[nr]] = 0;
+    if (tid < 4) s->cells[s->gw[nr] + tid] = 0;
     for (uint32_t t = tid; t < 2 * GTZ_SEGS * GTZ_KEYS; t += GTZ_THREADS) s->tabs[t] = ((t / GTZ_KEYS) & 1u) ? 0u : 0xFFFFFFFFu;
-    if (!HIST) {
-        s->lit[tid] = ct->lit[tid];
-        s->len[tid] = ct->len[tid];
-        if (tid < 32) s->dist[tid] = ct->dist[tid];
+    if (HIST) {
+        for (uint32_t t = tid; t < GTZ_NSYM; t += GTZ_THREADS) s->hist()[t] = 0;
+    } else {
+        s->lit()[tid] = ct->lit[tid];
+        s->len()[tid] = ct->len[tid];
+        if (tid < 32) s->dist()[tid] = ct->dist[tid];
         s->crc_table[tid] = p.tables->crc_table[tid];
         if (tid <= GTZ_CHUNK_CELLS) s->crc_base[tid] = p.tables->crc_base[tid];
         if (tid < GTZ_CHUNK_CELLS) { s->crc_unit_a[tid] = p.tables->crc_unit_a[tid]; s->crc_unit_b[tid] = p.tables->crc_unit_b[tid]; }
@@ -424,23 +379,38 @@ __global__ __launch_bounds__(GTZ_THREADS) void gtz_encode(const GtzParams p)
         const uint32_t kb = s->kb[i], ke = s->ke[i];
         if (ke - kb < GTZ_KEY_CELLS) continue;
         const uint32_t gbase = 16u * s->gw[i] - 16u * s->kw0[i];
-        for (uint32_t k = kb + tid; k + GTZ_KEY_CELLS <= ke; k += GTZ_THREADS) {
+        // Lanes hold consecutive positions.  Of a run of equal keys only its first position can be the
+        // earliest and only its last the latest, so the others stay away from the table: long stretches of
+        // "0/0" would otherwise send every lane's atomic to one LDS address.
+        for (uint32_t kk = kb; kk + GTZ_KEY_CELLS <= ke; kk += GTZ_THREADS) {
+            const uint32_t k = kk + tid;
+            const bool live = k + GTZ_KEY_CELLS <= ke;
             const uint32_t g = gbase + k;
-            const uint32_t key = gtz_window(s->cells, g) & (GTZ_KEYS - 1u);
-            const uint32_t q = min(g >> GTZ_SEG_SHIFT, GTZ_SEGS - 1u);
-            atomicMin(&s->tabs[(2u * q) * GTZ_KEYS + key], g);
-            atomicMax(&s->tabs[(2u * q + 1u) * GTZ_KEYS + key], g + 1u);
+            const uint32_t slot = live ? (min(g >> GTZ_SEG_SHIFT, GTZ_SEGS - 1u) << 11) | (gtz_window(s->cells, g) & (GTZ_KEYS - 1u)) : 0xFFFFFFFFu;
+            const uint32_t before = __shfl_up(slot, 1, 64), after = __shfl_down(slot, 1, 64);
+            const uint32_t lane = tid & 63u;
+            if (live && (lane == 0u || before != slot)) atomicMin(&s->tabs[(slot >> 11) * 2u * GTZ_KEYS + (slot & (GTZ_KEYS - 1u))], g);
+            if (live && (lane == 63u || after != slot)) atomicMax(&s->tabs[((slot >> 11) * 2u + 1u) * GTZ_KEYS + (slot & (GTZ_KEYS - 1u))], g + 1u);
         }
     }
     __syncthreads();
 
-    // ---- pass 1: tokenise, count bits (or symbols), CRC ----
+    // code lengths of the four literals a cell is made of, one byte each
+    const uint32_t lit_bits = HIST ? 0u : (s->lit()['0'] & 31u) | ((s->lit()['1'] & 31u) << 8) | ((s->lit()['/'] & 31u) << 16) | ((s->lit()['\t'] & 31u) << 24);
+    // ---- pass 1: search, then tokenise to count bits (or symbols); CRC ----
     uint32_t bits[2] = {0, 0}, part = 0;
-    uint32_t it_row[2], it_k0[2], it_k1[2];
+    uint32_t it_row[2];
+    bool it_span[2];
+    GtzChunk ch[2];
+    const uint32_t* it_far[2];
+    GtzTokens tks[2];
+#pragma unroll
     for (int u = 0; u < 2; ++u) {
         const uint32_t it = tid + (uint32_t)u * GTZ_THREADS;
         it_row[u] = 0xFFFFFFFFu;
-        it_k0[u] = it_k1[u] = 0;
+        it_span[u] = false;
+        it_far[u] = s->far;
+        ch[u] = GtzChunk{0, 0, 0, 0, 0, 0, false};
         if (it >= n_items) continue;
         uint32_t i = 0;
         while (i < nr && s->item_base[i + 1] <= it) ++i; // row (or nr: the closing span)
@@ -451,7 +421,7 @@ __global__ __launch_bounds__(GTZ_THREADS) void gtz_encode(const GtzParams p)
         if (local == 0u) {
             // literal span: bytes between two rows' cell regions
             const int32_t lo = s->span_lo[i], hi = s->span_hi[i];
-            it_k0[u] = 0xFFFFFFFFu;
+            it_span[u] = true;
             uint32_t c = 0xFFFFFFFFu;
             GtzCount cnt{s, 0};
             GtzHist hs{s};
@@ -468,31 +438,27 @@ __global__ __launch_bounds__(GTZ_THREADS) void gtz_encode(const GtzParams p)
             const uint32_t kb = s->kb[i], ke = s->ke[i];
             const uint32_t c64 = (kb >> 6) + local - 1u;
             const uint32_t k0 = max(kb, 64u * c64), k1 = min(ke, 64u * c64 + 64u);
-            it_k0[u] = k0;
-            it_k1[u] = k1;
             uint32_t* farlist = s->far + (s->chunk_base[i] + local - 1u) * GTZ_MAX_FAR;
+            it_far[u] = farlist;
+            ch[u] = gtz_load_chunk(s, i, c64, k0, k1);
+            gtz_find_matches(s, i, c64, ch[u], farlist);
+            tks[u] = gtz_tokens(ch[u], farlist);
+            const GtzTokens& tk = tks[u];
             if (HIST) {
-                GtzHist hs{s};
-                gtz_walk_chunk<true>(s, i, k0, k1, farlist, hs);
+                GtzSymbolCount hs{s->hist()};
+                gtz_emit_tokens(ch[u], tk, farlist, hs);
             } else {
-                GtzCount cnt{s, 0};
-                gtz_walk_chunk<true>(s, i, k0, k1, farlist, cnt);
-                bits[u] = cnt.bits;
-                // CRC of the chunk's 4 (k1 - k0) bytes from its cells: base pattern + one unit per '1'
+                GtzBitCount cnt{lit_bits, {ct->len_nb[0], ct->len_nb[1]}, {ct->dist_nb[0], ct->dist_nb[1]}, 0};
+                bits[u] = gtz_count_bits(ch[u], tk, farlist, cnt);
+                // CRC of the chunk's bytes from its cells: base pattern + one unit per '1'
                 const uint32_t n = k1 - k0;
-                const uint32_t gbase = 16u * s->gw[i] - 16u * s->kw0[i];
-                uint32_t c = s->crc_base[n];
-                for (uint32_t e = 0; e < n; e += 16u) {
-                    // cells k1-1-e .. k1-16-e, i.e. the window that ends at cell k1-e
-                    const uint32_t cnt16 = min(16u, n - e);
-                    const uint32_t w = gtz_window(s->cells, gbase + k1 - e - cnt16);
-                    for (uint32_t t = 0; t < cnt16; ++t) {
-                        const uint32_t code = (w >> (2u * (cnt16 - 1u - t))) & 3u;
-                        if (code & 1u) c ^= s->crc_unit_a[e + t];
-                        if (code & 2u) c ^= s->crc_unit_b[e + t];
-                    }
+                uint32_t cc = s->crc_base[n];
+                for (uint32_t e = 0; e < n; ++e) {
+                    const uint32_t code = ch[u].code(ch[u].j1 - 1u - e);
+                    cc ^= (code & 1u) ? s->crc_unit_a[e] : 0u;
+                    cc ^= (code & 2u) ? s->crc_unit_b[e] : 0u;
                 }
-                crc = c;
+                crc = cc;
                 nbytes = 4u * n;
                 end_byte = s->cs[i] + 4 * (int32_t)k1;
             }
@@ -508,7 +474,7 @@ __global__ __launch_bounds__(GTZ_THREADS) void gtz_encode(const GtzParams p)
     if (HIST) {
         __syncthreads();
         for (uint32_t t = tid; t < GTZ_NSYM; t += GTZ_THREADS)
-            if (s->hist[t]) atomicAdd(&p.hist[klass * GTZ_NSYM + t], s->hist[t]);
+            if (s->hist()[t]) atomicAdd(&p.hist[klass * GTZ_NSYM + t], s->hist()[t]);
         if (tid == 0) atomicAdd(&p.hist[klass * GTZ_NSYM + 256u], 1u); // end of block
         return;
     }
@@ -564,20 +530,20 @@ __global__ __launch_bounds__(GTZ_THREADS) void gtz_encode(const GtzParams p)
         atomicOr(&s->tabs[(BIT0 >> 5) + tid], v << (BIT0 & 31u));
         atomicOr(&s->tabs[(BIT0 >> 5) + tid + 1u], v >> (32u - (BIT0 & 31u)));
     }
+#pragma unroll
     for (int u = 0; u < 2; ++u) {
         const uint32_t i = it_row[u];
         if (i == 0xFFFFFFFFu) continue;
         const uint32_t start = BIT0 + hdr_bits + (u == 0 ? base0 + incl0 - bits[0] : tot0 + base1 + incl1 - bits[1]);
-        GtzEmit e{s, 0, start & 31u, start >> 5};
-        if (it_k0[u] == 0xFFFFFFFFu) {
+        if (it_span[u]) {
+            GtzEmit e{s, 0, start & 31u, start >> 5};
             for (int32_t pos = s->span_lo[i]; pos < s->span_hi[i]; ++pos) e.lit(gtz_text_byte(p, s, m_row, i, pos));
+            e.flush();
         } else {
-            const uint32_t it = tid + (uint32_t)u * GTZ_THREADS;
-            const uint32_t local = it - s->item_base[i];
-            uint32_t* farlist = s->far + (s->chunk_base[i] + local - 1u) * GTZ_MAX_FAR;
-            gtz_walk_chunk<false>(s, i, it_k0[u], it_k1[u], farlist, e);
+            GtzBitEmit e{s->tabs, s->len(), s->dist(), {s->lit()['0'], s->lit()['1'], s->lit()['/'], s->lit()['\t']}, 0, start & 31u, start >> 5};
+            gtz_emit_tokens(ch[u], tks[u], it_far[u], e);
+            e.flush();
         }
-        e.flush();
     }
     if (tid == 0) {
         const uint32_t start = BIT0 + hdr_bits + total;

@@ -1,0 +1,318 @@
+// gtz_tokens.hip.h -- search and tokenisation of one 64-cell chunk for the genotype-domain BGZF encoder,
+// written so that the lanes of a wave stay together: the chunk's state is a handful of bit masks in
+// registers, loops run over events (breaks, tokens) rather than cells, and literals need no LDS access.
+//
+// Byte view of a chunk: 256 text bytes = 4 words of 64 bits, bit i of word w = byte 64 w + i.  Byte i of a
+// cell-aligned word belongs to cell i >> 2; bytes 0 and 2 of a cell are the alleles, 1 is '/', 3 is '\t'.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace dnaf {
+
+// spread the 32 bits of v to the even... every 2-bit group of v to the low half of a nibble of the result
+__device__ __forceinline__ uint64_t gtz_spread_pairs(uint32_t v)
+{
+    uint64_t t = v;
+    t = (t | (t << 16)) & 0x0000FFFF0000FFFFull;
+    t = (t | (t << 8)) & 0x00FF00FF00FF00FFull;
+    t = (t | (t << 4)) & 0x0F0F0F0F0F0F0F0Full;
+    t = (t | (t << 2)) & 0x3333333333333333ull;
+    return t;
+}
+
+// bits [lo, hi) of a 256-bit mask, word w of it
+__device__ __forceinline__ uint64_t gtz_range_word(uint32_t lo, uint32_t hi, uint32_t w)
+{
+    const uint32_t base = 64u * w;
+    const uint32_t a = lo > base ? lo - base : 0u, b = hi > base ? hi - base : 0u;
+    return gtz_low_mask(min(b, 64u)) & ~gtz_low_mask(min(a, 64u));
+}
+
+// Token masks of a chunk.  run3: bytes inside distance-4 matches (runs of >= 3 repeating bytes outside the
+// LZ77 matches); plain: bytes that are tokens of their own or inside a distance-4 match (valid and not
+// covered by an LZ77 match); far: first byte of each recorded LZ77 match.
+struct GtzTokens {
+    uint64_t run3[4], plain[4], far[4];
+};
+
+__device__ __forceinline__ GtzTokens gtz_tokens(const GtzChunk& c, const uint32_t* farlist)
+{
+    GtzTokens t;
+    uint64_t M[4];
+    const uint32_t lo = 4u * c.j0, hi = 4u * c.j1;
+    const uint32_t xs[4] = {(uint32_t)c.xlo, (uint32_t)(c.xlo >> 32), (uint32_t)c.xhi, (uint32_t)(c.xhi >> 32)};
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        const uint64_t s = gtz_spread_pairs(xs[w]);                                     // [xa, xb, 0, 0] per cell
+        const uint64_t brk = (s & 0x1111111111111111ull) | ((s & 0x2222222222222222ull) << 1); // allele bytes that differ
+        t.plain[w] = gtz_range_word(lo, hi, (uint32_t)w);
+        M[w] = ~brk & t.plain[w];
+        t.far[w] = 0;
+    }
+    if (c.head) { // the region's first cell: its '/' and '\t' have nothing to repeat either
+#pragma unroll
+        for (int w = 0; w < 4; ++w) M[w] &= ~gtz_range_word(lo, lo + 4u, (uint32_t)w);
+    }
+    for (uint32_t n = 0; n < GTZ_MAX_FAR; ++n) {
+        const uint32_t e = farlist[n];
+        if (!(e >> 6)) break;
+        const uint32_t a = lo + 4u * (e & 63u), b = a + 4u * ((e >> 6) & 127u);
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const uint64_t r = gtz_range_word(a, b, (uint32_t)w);
+            t.plain[w] &= ~r;
+            M[w] &= ~r;
+            t.far[w] |= gtz_range_word(a, a + 1u, (uint32_t)w);
+        }
+    }
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        const uint64_t below = w ? M[w - 1] : 0ull, above = w < 3 ? M[w + 1] : 0ull;
+        const uint64_t up = (M[w] << 1) | (below >> 63), up2 = (M[w] << 2) | (below >> 62);
+        const uint64_t dn = (M[w] >> 1) | (above << 63), dn2 = (M[w] >> 2) | (above << 62);
+        t.run3[w] = M[w] & ((up & up2) | (up & dn) | (dn & dn2));
+    }
+    return t;
+}
+
+// Sinks receive literals as a kind (0 '0', 1 '1', 2 '/', 3 '\t') and matches as (length, distance in bytes).
+struct GtzBitCount {
+    uint32_t lit_bits;   // 4 x 8 bits: code length of each literal kind
+    uint64_t len_nb[2];  // 29 nibbles: code length of length symbol 257 + n
+    uint64_t dist_nb[2]; // 30 nibbles: code length of distance symbol n
+    uint32_t bits;
+    __device__ __forceinline__ void lit(uint32_t kind) { bits += (lit_bits >> (8u * kind)) & 0xFFu; }
+    __device__ __forceinline__ void match(uint32_t L, uint32_t d)
+    {
+        const uint32_t ls = gtz_len_symbol(L) - 257u;
+        uint32_t sym, eb, ev;
+        gtz_dist_symbol(d, &sym, &eb, &ev);
+        const uint32_t lb = (uint32_t)(len_nb[ls >> 4] >> (4u * (ls & 15u))) & 15u;
+        const uint32_t db = (uint32_t)(dist_nb[sym >> 4] >> (4u * (sym & 15u))) & 15u;
+        const uint32_t leb = (ls < 8u || ls == 28u) ? 0u : (ls - 4u) >> 2;
+        bits += lb + leb + db + eb;
+    }
+};
+
+struct GtzSymbolCount {
+    uint32_t* hist; // LDS [GTZ_NSYM]
+    __device__ __forceinline__ void lit(uint32_t kind)
+    {
+        const uint32_t b = kind == 0u ? '0' : kind == 1u ? '1' : kind == 2u ? '/' : '\t';
+        atomicAdd(&hist[b], 1u);
+    }
+    __device__ __forceinline__ void match(uint32_t L, uint32_t d)
+    {
+        uint32_t sym, eb, ev;
+        gtz_dist_symbol(d, &sym, &eb, &ev);
+        atomicAdd(&hist[gtz_len_symbol(L)], 1u);
+        atomicAdd(&hist[GTZ_DIST0 + sym], 1u);
+    }
+};
+
+struct GtzBitEmit {
+    uint32_t* image;       // LDS bit buffer (zero-initialised), written with atomic OR
+    const uint32_t* len;   // LDS: match length -> code + extra bits
+    const uint32_t* dist;  // LDS: distance symbol -> code
+    uint32_t lit_entry[4]; // the four literal kinds' codes
+    uint64_t acc;
+    uint32_t nacc, word;
+    __device__ __forceinline__ void put(uint32_t v, uint32_t n)
+    {
+        acc |= (uint64_t)v << nacc;
+        nacc += n;
+        if (nacc >= 32u) {
+            atomicOr(&image[word], (uint32_t)acc);
+            ++word;
+            acc >>= 32;
+            nacc -= 32u;
+        }
+    }
+    __device__ __forceinline__ void entry(uint32_t e) { put(e >> 5, e & 31u); }
+    __device__ __forceinline__ void lit(uint32_t kind)
+    {
+        const uint32_t e = kind == 0u ? lit_entry[0] : kind == 1u ? lit_entry[1] : kind == 2u ? lit_entry[2] : lit_entry[3];
+        entry(e);
+    }
+    __device__ __forceinline__ void match(uint32_t L, uint32_t d)
+    {
+        uint32_t sym, eb, ev;
+        gtz_dist_symbol(d, &sym, &eb, &ev);
+        const uint32_t le = len[L - 3u], de = dist[sym];
+        entry(le);
+        entry(de);
+        if (eb) put(ev, eb);
+    }
+    __device__ __forceinline__ void flush()
+    {
+        if (nacc) atomicOr(&image[word], (uint32_t)acc);
+    }
+};
+
+// Deflate bits of the chunk's tokens without visiting the literals: their four kinds are counted with
+// popcounts, only the matches are walked.
+__device__ __forceinline__ uint32_t gtz_count_bits(const GtzChunk& c, const GtzTokens& t, const uint32_t* farlist, GtzBitCount& cnt)
+{
+    const uint32_t codes[4] = {(uint32_t)c.lo, (uint32_t)(c.lo >> 32), (uint32_t)c.hi, (uint32_t)(c.hi >> 32)};
+    uint32_t n_zero = 0, n_one = 0, n_slash = 0, n_tab = 0, nfar = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        const uint64_t r = t.run3[w];
+        const uint64_t lit = t.plain[w] & ~r;
+        const uint64_t sp = gtz_spread_pairs(codes[w]);
+        const uint64_t ones = (sp & 0x1111111111111111ull) | ((sp & 0x2222222222222222ull) << 1); // allele bytes that are '1'
+        n_one += (uint32_t)__builtin_popcountll(lit & ones);
+        n_zero += (uint32_t)__builtin_popcountll(lit & 0x5555555555555555ull & ~ones);
+        n_slash += (uint32_t)__builtin_popcountll(lit & 0x2222222222222222ull);
+        n_tab += (uint32_t)__builtin_popcountll(lit & 0x8888888888888888ull);
+        const uint64_t carry = w ? t.run3[w - 1] >> 63 : 0ull;
+        uint64_t T = (r & ~((r << 1) | carry)) | t.far[w];
+        while (T) {
+            const uint32_t p = (uint32_t)__builtin_ctzll(T);
+            T &= T - 1ull;
+            if (t.far[w] & (1ull << p)) {
+                const uint32_t e = farlist[nfar++];
+                cnt.match(4u * ((e >> 6) & 127u), e >> 13);
+            } else {
+                uint32_t L;
+                const uint64_t stop = ~r & ~gtz_low_mask(p);
+                if (stop) L = (uint32_t)__builtin_ctzll(stop) - p;
+                else {
+                    L = 64u - p;
+#pragma unroll
+                    for (int v = w + 1; v < 4; ++v) {
+                        const uint32_t more = ~t.run3[v] ? (uint32_t)__builtin_ctzll(~t.run3[v]) : 64u;
+                        const bool go = L == 64u * (uint32_t)(v - w) - p;
+                        L += go ? more : 0u;
+                    }
+                }
+                cnt.match(L, 4u);
+            }
+        }
+    }
+    const uint32_t lb = cnt.lit_bits;
+    cnt.bits += n_zero * (lb & 0xFFu) + n_one * ((lb >> 8) & 0xFFu) + n_slash * ((lb >> 16) & 0xFFu) + n_tab * (lb >> 24);
+    return cnt.bits;
+}
+
+// Visit the chunk's tokens in byte order.
+template <class Sink>
+__device__ __forceinline__ void gtz_emit_tokens(const GtzChunk& c, const GtzTokens& t, const uint32_t* farlist, Sink& sink)
+{
+    const uint32_t codes[4] = {(uint32_t)c.lo, (uint32_t)(c.lo >> 32), (uint32_t)c.hi, (uint32_t)(c.hi >> 32)};
+    uint32_t nfar = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        const uint64_t r = t.run3[w];
+        const uint64_t carry = w ? t.run3[w - 1] >> 63 : 0ull;
+        const uint64_t mstart = r & ~((r << 1) | carry);
+        uint64_t T = (t.plain[w] & ~r) | mstart | t.far[w];
+        while (T) {
+            const uint32_t p = (uint32_t)__builtin_ctzll(T);
+            T &= T - 1ull;
+            const uint64_t bit = 1ull << p;
+            if (t.far[w] & bit) {
+                const uint32_t e = farlist[nfar++];
+                sink.match(4u * ((e >> 6) & 127u), e >> 13);
+            } else if (r & bit) {
+                // distance-4 match: runs on through the following words while their low bytes stay in the run
+                uint32_t L;
+                const uint64_t stop = ~r & ~gtz_low_mask(p); // first byte at or after p that is not in the run
+                if (stop) L = (uint32_t)__builtin_ctzll(stop) - p;
+                else {
+                    L = 64u - p;
+#pragma unroll
+                    for (int v = w + 1; v < 4; ++v) {
+                        const uint32_t more = ~t.run3[v] ? (uint32_t)__builtin_ctzll(~t.run3[v]) : 64u;
+                        const bool go = L == 64u * (uint32_t)(v - w) - p; // still contiguous up to word v
+                        L += go ? more : 0u;
+                    }
+                }
+                sink.match(L, 4u);
+            } else {
+                const uint32_t which = p & 3u;
+                const uint32_t allele = (codes[w] >> (p >> 1)) & 1u;
+                sink.lit((which & 1u) ? 2u + (which >> 1) : allele);
+            }
+        }
+    }
+}
+
+// LZ77 matches of one chunk (see gtz_kernels.hip.h).  Lanes step from break to break together; a break is
+// only looked up when the 16 cells from it hold at least GTZ_MIN_BREAKS differing alleles.
+__device__ __forceinline__ void gtz_find_matches(GtzShared* s, uint32_t i, uint32_t c64, const GtzChunk& c, uint32_t* farlist)
+{
+    const uint32_t gbase = 16u * s->gw[i] - 16u * s->kw0[i] + 64u * c64; // g of the chunk's cell 0
+    const uint32_t grow = 16u * s->gw[i];                                // first g of this row
+    const int32_t cs = s->cs[i];
+    const uint64_t blo = (c.xlo | (c.xlo >> 1)) & 0x5555555555555555ull;
+    const uint64_t bhi = (c.xhi | (c.xhi >> 1)) & 0x5555555555555555ull;
+    if (c.j1 < GTZ_KEY_CELLS + c.j0) { farlist[0] = 0; return; }
+    const uint32_t last = c.j1 - GTZ_KEY_CELLS; // last cell a match can start at
+    uint32_t pos = c.j0, nfar = 0;
+    for (;;) {
+        const uint32_t j = gtz_next_break(blo, bhi, pos);
+        if (j > last || nfar >= GTZ_MAX_FAR) break;
+        // alleles that differ from the cell before, in the 16 cells from j
+        const uint32_t xw = j < 32u ? (uint32_t)((c.xlo >> (2u * j)) | (j ? c.xhi << (64u - 2u * j) : 0ull)) : (uint32_t)(c.xhi >> (2u * j - 64u));
+        if ((uint32_t)__builtin_popcount(xw) < GTZ_MIN_BREAKS) { pos = j + 1u; continue; }
+        const uint32_t g = gbase + j;
+        const uint32_t dw = c.window(j);
+        const uint32_t key = dw & (GTZ_KEYS - 1u);
+        const uint32_t q = min(g >> GTZ_SEG_SHIFT, GTZ_SEGS - 1u);
+        const uint32_t c0 = s->tabs[(2u * q) * GTZ_KEYS + key];
+        const uint32_t c1 = q ? s->tabs[(2u * (q - 1u) + 1u) * GTZ_KEYS + key] - 1u : 0xFFFFFFFFu;
+        const uint32_t room = c.j1 - j;
+        const bool ok0 = c0 < g, ok1 = c1 < g;
+        const uint32_t s0 = ok0 ? c0 : g, s1 = ok1 ? c1 : g; // a disabled candidate reads its own position
+        const uint32_t w0 = gtz_window(s->cells, s0), w1 = gtz_window(s->cells, s1);
+        uint32_t n0 = (w0 ^ dw) ? (uint32_t)__builtin_ctz(w0 ^ dw) >> 1 : 16u;
+        uint32_t n1 = (w1 ^ dw) ? (uint32_t)__builtin_ctz(w1 ^ dw) >> 1 : 16u;
+        uint32_t lim0 = room, lim1 = room, d0 = 4u * (g - s0), d1 = 4u * (g - s1);
+        if ((ok0 && s0 < grow) || (ok1 && s1 < grow)) { // a source in an earlier row of the member: its own byte distance and end
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const uint32_t sg = t ? s1 : s0;
+                if (!(t ? ok1 : ok0) || sg >= grow) continue;
+                uint32_t r = i;
+                while (16u * s->gw[r] > sg) --r;
+                const uint32_t ks = sg - 16u * s->gw[r] + 16u * s->kw0[r];
+                const uint32_t d = (uint32_t)(cs + 4 * (int32_t)(64u * c64 + j) - (s->cs[r] + 4 * (int32_t)ks));
+                const uint32_t lim = min(room, s->ke[r] - ks);
+                if (t) { d1 = d; lim1 = lim; } else { d0 = d; lim0 = lim; }
+            }
+        }
+        // longer than one window: keep comparing (rare except in sparse rows)
+        if (ok0 && n0 == 16u)
+            while (n0 < lim0) {
+                const uint32_t x = c.window(j + n0) ^ gtz_window(s->cells, s0 + n0);
+                if (x) { n0 += (uint32_t)__builtin_ctz(x) >> 1; break; }
+                n0 += 16u;
+            }
+        if (ok1 && n1 == 16u)
+            while (n1 < lim1) {
+                const uint32_t x = c.window(j + n1) ^ gtz_window(s->cells, s1 + n1);
+                if (x) { n1 += (uint32_t)__builtin_ctz(x) >> 1; break; }
+                n1 += 16u;
+            }
+        n0 = (ok0 && d0 <= 32768u) ? min(n0, lim0) : 0u;
+        n1 = (ok1 && d1 <= 32768u) ? min(n1, lim1) : 0u;
+        const bool first = n0 > n1 || (n0 == n1 && d0 <= d1);
+        const uint32_t f = first ? n0 : n1, dbytes = first ? d0 : d1;
+        bool take = f >= GTZ_KEY_CELLS;
+        if (take) {
+            const uint32_t a = 2u * j, b = 2u * (j + f);
+            const uint64_t mlo = gtz_low_mask(min(b, 64u)) & ~gtz_low_mask(min(a, 64u));
+            const uint64_t mhi = gtz_low_mask(b > 64u ? b - 64u : 0u) & ~gtz_low_mask(a > 64u ? a - 64u : 0u);
+            take = (uint32_t)(__builtin_popcountll(c.xlo & mlo) + __builtin_popcountll(c.xhi & mhi)) >= GTZ_MIN_BREAKS;
+        }
+        if (take) {
+            farlist[nfar++] = (j - c.j0) | (f << 6) | (dbytes << 13);
+            pos = j + f;
+        } else pos = j + 1u;
+    }
+    if (nfar < GTZ_MAX_FAR) farlist[nfar] = 0; // terminator: a recorded match has cells != 0
+}
+
+} // namespace dnaf

@@ -197,3 +197,97 @@ def test_gpu_bgzf_stored_fallback_on_incompressible_text(capi):
     members = _members(raw)
     full = [m for m in members if len(m) == 61440 + 5 + 26]
     assert len(full) >= 2 and all(m[18] == 1 for m in full)  # BFINAL=1, BTYPE=00
+
+
+# ---- genotype-domain members (gtz_kernels.hip.h): made from the packed matrix, checked like the others ----
+def _sorted_case(S, n, seed, min_maf=0.01):
+    from dna_factory_amd import genome
+    from dna_factory_amd.tables import SampleTable
+
+    rs = np.random.RandomState(seed)
+    tb = genome.synthetic_snp_table(n, min_maf=min_maf, rs=rs)
+    flags = (rs.rand(S) <= 0.5).astype(np.uint8) | (np.arange(S) < S // 2).astype(np.uint8) * 2
+    return tb, SampleTable(flags)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("S,n", [(2, 9000), (3, 7000), (17, 3000), (700, 400), (950, 300), (2000, 300), (15360, 40),
+                                 (20000, 120), (20001, 60), (100003, 12)])
+def test_gtz_members_inflate_to_the_text(capi, S, n):
+    """Rows sorted as the CLI sorts them (autosomes, then MT / X / Y): most members are made from the genotype
+    matrix, the ones that touch other chromosome classes from the text; every one must inflate to the text."""
+    from dna_factory_amd.rowgen import RowGenerator
+
+    tb, st = _sorted_case(S, n, seed=S + n)
+    with RowGenerator(device=0, seed=11) as g:
+        g.set_samples(st)
+        g.set_snps(tb)
+        text, _, _ = g.generate(text=True, packed=False)
+        blob, n_text = g.generate_bgzf()
+        blob_again, _ = g.generate_bgzf(reuse_tables=True)
+        blob_text, _ = g.generate_bgzf(text_domain=True)
+    want = text.tobytes()
+    assert n_text == len(want)
+    for b in (blob, blob_again, blob_text):
+        assert gzip.decompress(b.tobytes()) == want
+    members = _members(blob.tobytes())
+    assert len(members) == -(-len(want) // 61440) and max(len(m) for m in members) <= 65536
+    if S >= 2000:
+        assert len(blob) < 0.85 * len(blob_text)  # LZ77 matches over cells beat the distance-4-only coder
+
+
+@pytest.mark.gpu
+def test_gtz_row_ranges_forced_cells_and_multiallelic_rows(capi):
+    """Ranges that do not start at row 0 (text_base != 0), carriers forced to 1/1, and rows with three alleles in
+    between (those members fall back to the text-domain encoder)."""
+    from dna_factory_amd.rowgen import RowGenerator
+    from dna_factory_amd.tables import SampleTable
+
+    S, n = 5000, 400
+    tb, st = _sorted_case(S, n, seed=3)
+    autosome = np.flatnonzero(tb.chrom_class == 0)
+    forced = [int(tb.snp_id[autosome[5]]), int(tb.snp_id[autosome[40]])]
+    carriers = np.arange(S // 2, S, 3, dtype=np.uint32)
+    st = SampleTable(st.flags, forced, [0, len(carriers), 2 * len(carriers)], np.concatenate([carriers, carriers]))
+    tb.alt = tb.alt.astype("S3")
+    for j in autosome[100:110]:  # three alleles: cells may hold '2'
+        tb.n_alleles[j] = 3
+        tb.cum[j] = [0.6, 0.8, 1.0, 1.0]
+        tb.alt[j] = b"C,G" if tb.ref[j] not in (b"C", b"G") else b"A,T"
+    with RowGenerator(device=0, seed=5) as g:
+        g.set_samples(st)
+        g.set_snps(tb)
+        for b, m in ((0, n), (7, 150), (95, 30), (n - 20, 20), (33, 1)):
+            text, _, _ = g.generate(b, m, text=True, packed=False)
+            blob, n_text = g.generate_bgzf(b, m)
+            assert n_text == len(text)
+            assert gzip.decompress(blob.tobytes()) == text.tobytes()
+        # the forced rows really are 1/1 for the carriers in what was compressed
+        text, off, _ = g.generate(text=True, packed=False)
+        row = int(np.flatnonzero(tb.snp_id == forced[0])[0])
+        line = text[int(off[row]): int(off[row + 1])].tobytes().rstrip(b"\n").split(b"\t")[9:]
+        assert all(line[i] == b"1/1" for i in carriers[:50])
+
+
+@pytest.mark.gpu
+def test_gtz_extreme_rows(capi):
+    """All-reference rows (one long distance-4 run), rows at MAF 0.5 (dense LZ77 matches) and an alternating
+    pattern forced through the deleterious set: sizes stay within BGZF's 64 KiB and everything inflates."""
+    from dna_factory_amd.rowgen import RowGenerator
+    from dna_factory_amd.tables import SampleTable, SnpTable
+
+    S, n = 20000, 24
+    cum = np.ones((n, 4))
+    cum[:, 0] = np.where(np.arange(n) % 3 == 0, 1.0, np.where(np.arange(n) % 3 == 1, 0.5, 0.995))
+    tb = SnpTable(np.arange(1, n + 1), np.full(n, b"2", dtype="S2"), np.arange(n) * 100 + 1, np.full(n, b"A", dtype="S1"),
+                  np.full(n, b"T", dtype="S1"), np.full(n, 2, np.uint8), cum)
+    flags = np.zeros(S, np.uint8)  # all cases, all female
+    carriers = np.arange(0, S, 2, dtype=np.uint32)  # every other sample is 1/1 on row 0: "1/1\t0/0\t" repeated
+    st = SampleTable(flags, [1], [0, len(carriers)], carriers)
+    with RowGenerator(device=0, seed=1) as g:
+        g.set_samples(st)
+        g.set_snps(tb)
+        text, _, _ = g.generate(text=True, packed=False)
+        blob, _ = g.generate_bgzf()
+    assert gzip.decompress(blob.tobytes()) == text.tobytes()
+    assert text[:200].tobytes().count(b"1/1\t0/0\t") > 10
