@@ -33,7 +33,7 @@ SYMBOLS = [
     "dnaf_reserve_output",
     "dnaf_sync", "dnaf_last_generate_ms", "dnaf_timing_begin", "dnaf_timing_end", "dnaf_read_text", "dnaf_read_packed", "dnaf_device_buffers",
     "dnaf_format_prefixes", "dnaf_bgzf_compress", "dnaf_read_bgzf", "dnaf_last_bgzf_ms",
-    "dnaf_bgzf_tables_from_histogram", "dnaf_set_mt_state", "dnaf_mt_jump_host", "dnaf_mt_characteristic_polynomial",
+    "dnaf_bgzf_tables_from_histogram", "dnaf_gtz_tables_from_histogram", "dnaf_set_mt_state", "dnaf_mt_jump_host", "dnaf_mt_characteristic_polynomial",
     "dnaf_fetch_bgzf", "dnaf_fetch_text", "dnaf_read_text_range", "dnaf_format_snps_json", "dnaf_parse_snps_json",
     "dnaf_allele_counts",
 ]
@@ -91,6 +91,7 @@ def _load():
         "dnaf_read_bgzf": (ci, [vp, vp, u64, vp]),
         "dnaf_last_bgzf_ms": (ci, [vp, vp]),
         "dnaf_bgzf_tables_from_histogram": (ci, [vp, vp, u64, vp, u64, vp]),
+        "dnaf_gtz_tables_from_histogram": (ci, [vp, vp, u64, vp]),
         "dnaf_set_mt_state": (ci, [vp, vp, u32, u64]),
         "dnaf_fetch_bgzf": (ci, [vp, vp, vp]),
         "dnaf_fetch_text": (ci, [vp, vp, vp]),

@@ -1079,6 +1079,15 @@ int dnaf_bgzf_tables_from_histogram(const uint64_t* lit_hist, const uint64_t* ma
     return DNAF_OK;
 }
 
+// Host-only: the genotype-domain encoder's tables for hist[8][320] (per class: 286 literal/length symbol counts, then
+// 30 distance symbol counts).  out must hold sizeof(GtzTables) bytes; *size receives that size.
+int dnaf_gtz_tables_from_histogram(const uint32_t* hist, void* out, uint64_t out_cap, uint64_t* size)
+{
+    if (size) *size = sizeof(dnaf::GtzTables);
+    if (!hist || !out || out_cap < sizeof(dnaf::GtzTables)) return DNAF_ERR_BAD_ARG;
+    return dnaf::gtz_build_tables(hist, (dnaf::GtzTables*)out) ? DNAF_OK : DNAF_ERR_UNSUPPORTED;
+}
+
 // ---- host helper: fixed columns of a VCF body line, pop_factory.py:503-507 ----
 static inline size_t put_i64(uint8_t* p, int64_t v)
 {

@@ -156,8 +156,11 @@ int dnaf_device_buffers(dnaf_ctx* ctx, void** d_text, uint64_t* text_bytes, void
 /* On-GPU BGZF encoder -- the sink right after the path (the reference pushes every line through
  * Bio.bgzf.BgzfWriter, pop_factory.py:403, :449).  Compresses the text of the last dnaf_generate
  * into a sequence of BGZF members (gzip members with the BC extra field, <= 64 KiB each, no EOF
- * block) in device memory; any gzip reader returns the input bytes.  flags: DNAF_BGZF_REUSE_TABLES
- * keeps the Huffman tables of the previous call instead of sampling the new text.  Synchronises. */
+ * block) in device memory; any gzip reader returns the input bytes.  When the range was generated
+ * with DNAF_OUT_TEXT | DNAF_OUT_PACKED, members that lie in biallelic autosome rows are encoded from
+ * the 2-bit matrix (LZ77 over cells, about 30 % smaller output); the decompressed bytes are the same.
+ * flags: DNAF_BGZF_REUSE_TABLES keeps the Huffman tables of the previous call instead of sampling
+ * the new rows.  Synchronises. */
 #define DNAF_BGZF_REUSE_TABLES 1u
 #define DNAF_BGZF_TEXT_DOMAIN 2u /* encode every member from the text (no genotype-domain members) */
 int dnaf_bgzf_compress(dnaf_ctx* ctx, uint32_t flags, uint64_t* n_bytes);
@@ -191,6 +194,10 @@ int dnaf_mt_jump_host(const uint32_t* base, uint64_t J, uint32_t* window);
 int dnaf_mt_characteristic_polynomial(uint64_t* words312, int* degree);
 int dnaf_bgzf_tables_from_histogram(const uint64_t* lit_hist, const uint64_t* match_hist, uint64_t n_eob, void* out,
                                     uint64_t out_cap, uint64_t* size);
+/* Host-only helper: the genotype-domain encoder's tables for hist[8][320] -- per table class 286
+ * literal/length symbol counts followed by 30 distance symbol counts (4 unused); out receives an
+ * opaque blob (code tables and run-length coded block header per class, CRC-32 unit tables). */
+int dnaf_gtz_tables_from_histogram(const uint32_t* hist, void* out, uint64_t out_cap, uint64_t* size);
 
 /* Host helper: format the fixed columns of each row exactly like
  * pop_factory.py:503-507 ("%s\t%i\trs%s\t%s\t%s\t40\tPASS\t.\tGT\t").

@@ -199,6 +199,96 @@ def test_gpu_bgzf_stored_fallback_on_incompressible_text(capi):
     assert len(full) >= 2 and all(m[18] == 1 for m in full)  # BFINAL=1, BTYPE=00
 
 
+def _gtz_tables(capi, hist):
+    import ctypes
+
+    h = np.ascontiguousarray(hist, dtype=np.uint32)
+    assert h.shape == (8, 320)
+    size = ctypes.c_uint64(0)
+    capi.lib.dnaf_gtz_tables_from_histogram(capi.ptr(h), None, 0, ctypes.byref(size))
+    blob = np.zeros(size.value // 4, dtype=np.uint32)
+    assert capi.lib.dnaf_gtz_tables_from_histogram(capi.ptr(h), capi.ptr(blob), size.value, ctypes.byref(size)) == 0
+    per = 256 + 256 + 32 + 2 + 64 + 8  # lit, len, dist, eob + hdr_nbits, hdr, two pairs of u64 nibble tables
+    classes = []
+    for c in range(8):
+        b = blob[c * per: (c + 1) * per]
+        nib = b[610:618].view(np.uint64)
+        classes.append({"lit": b[0:256], "len": b[256:512], "dist": b[512:544], "eob": int(b[544]), "hdr_nbits": int(b[545]),
+                        "hdr": b[546:610], "len_nb": nib[0:2], "dist_nb": nib[2:4]})
+    rest = blob[8 * per:]
+    t = {"cls": classes, "crc_table": rest[0:256], "crc_base": rest[256:321], "unit_a": rest[321:385], "unit_b": rest[385:449],
+         "shift_chunk": rest[449:1473], "shift_byte": rest[1473:1729]}
+    assert len(rest) in (1729, 1730)  # 8-byte struct alignment may add one pad word
+    return t
+
+
+def _dist_symbol(d):
+    t = d - 1
+    if t < 4:
+        return t, 0, 0
+    hb = t.bit_length() - 1
+    return 2 * hb + ((t >> (hb - 1)) & 1), hb - 1, t & ((1 << (hb - 1)) - 1)
+
+
+def test_gtz_tables_make_valid_deflate_streams(capi):
+    """Per-class code tables + run-length coded block header of the genotype-domain encoder: a token stream with
+    literals, every match length and distances from every distance symbol inflates to the data it describes."""
+    rs = np.random.RandomState(9)
+    hist = np.zeros((8, 320), dtype=np.uint32)
+    for c in range(8):
+        hist[c, ord("0")] = 40000 >> c
+        hist[c, ord("1")] = 300 << c
+        hist[c, ord("/")] = hist[c, ord("\t")] = 500 + 100 * c
+        hist[c, 256] = 10
+        hist[c, 257:286] = rs.randint(0, 2000, 29) if c != 3 else 0  # class 3: no match ever seen in the sample
+        hist[c, 286:316] = rs.randint(0, 500, 30) if c != 3 else 0
+    t = _gtz_tables(capi, hist)
+    for c in range(8):
+        k = t["cls"][c]
+        data = bytearray(rs.randint(0, 256, 40000).astype(np.uint8).tobytes())  # history for far matches
+        bits = Bits()
+        bits.put_words(k["hdr"], k["hdr_nbits"])
+        for b in data:
+            bits.put_entry(k["lit"][b])
+        for L in list(range(3, 259)) + [20, 24, 256]:
+            d = int(rs.choice([1, 2, 3, 4, 5, 8, 12, 100, 1000, 4096, 4097, 20000, 32768]))
+            sym, eb, ev = _dist_symbol(d)
+            for _ in range(L):
+                data.append(data[-d])
+            bits.put_entry(k["len"][L - 3])
+            bits.put_entry(k["dist"][sym])
+            bits.v |= ev << bits.n
+            bits.n += eb
+            data.append(ord("1"))
+            bits.put_entry(k["lit"][ord("1")])
+        bits.put_entry(k["eob"])
+        assert zlib.decompressobj(-15).decompress(bits.bytes()) == bytes(data), "class %d" % c
+        assert k["hdr_nbits"] < 700  # run-length coded: far below the 1338 bits of a flat 4-bit listing
+        # the nibble tables the bit-count pass uses agree with the code tables
+        for s_ in range(30):
+            assert (int(k["dist_nb"][s_ >> 4]) >> (4 * (s_ & 15))) & 15 == int(k["dist"][s_]) & 31
+        assert (int(k["len_nb"][0]) & 15) == int(k["len"][0]) & 31  # length 3 = symbol 257, no extra bits
+
+
+def test_gtz_crc_of_a_chunk_from_its_cells(capi):
+    """CRC-32 is affine: the CRC of n cells is the CRC of n x "0/0\\t" XOR one unit per '1' allele, indexed by the
+    cell's distance from the end of the chunk."""
+    t = _gtz_tables(capi, np.ones((8, 320), dtype=np.uint32))
+    rs = np.random.RandomState(2)
+    for n in (1, 2, 17, 63, 64):
+        codes = rs.randint(0, 4, n)
+        text = b"".join(b"%d/%d\t" % (c & 1, c >> 1) for c in codes)
+        crc = int(t["crc_base"][n])
+        for e in range(n):
+            c = codes[n - 1 - e]
+            if c & 1:
+                crc ^= int(t["unit_a"][e])
+            if c & 2:
+                crc ^= int(t["unit_b"][e])
+        assert crc == zlib.crc32(text)
+    assert int(t["crc_base"][0]) == 0
+
+
 # ---- genotype-domain members (gtz_kernels.hip.h): made from the packed matrix, checked like the others ----
 def _sorted_case(S, n, seed, min_maf=0.01):
     from dna_factory_amd import genome
