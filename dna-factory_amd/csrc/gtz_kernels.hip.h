@@ -47,6 +47,7 @@ constexpr uint32_t GTZ_CELL_WORDS = BGZF_IN / 64 + 2 * GTZ_MAX_ROWS + 8;
 constexpr uint32_t GTZ_STRIDE = 16384;    // staging slot of a member
 constexpr uint32_t GTZ_OUT_WORDS = GTZ_STRIDE / 4;
 constexpr uint32_t GTZ_MIN_BREAKS = 3;    // an LZ77 match must replace at least this many literal bytes
+constexpr uint32_t GTZ_CANDS = 4;         // source candidates looked at per break (2..4)
 static_assert(2 * GTZ_SEGS * GTZ_KEYS >= GTZ_OUT_WORDS, "the member image reuses the key tables");
 
 struct GtzParams {

@@ -261,45 +261,53 @@ __device__ __forceinline__ void gtz_find_matches(GtzShared* s, uint32_t i, uint3
         const uint32_t dw = c.window(j);
         const uint32_t key = dw & (GTZ_KEYS - 1u);
         const uint32_t q = min(g >> GTZ_SEG_SHIFT, GTZ_SEGS - 1u);
-        const uint32_t c0 = s->tabs[(2u * q) * GTZ_KEYS + key];
-        const uint32_t c1 = q ? s->tabs[(2u * (q - 1u) + 1u) * GTZ_KEYS + key] - 1u : 0xFFFFFFFFu;
+        // candidates: earliest in this quarter, latest / earliest in the one before, latest two back
+        uint32_t cand[GTZ_CANDS];
+        cand[0] = s->tabs[(2u * q) * GTZ_KEYS + key];
+        cand[1] = q ? s->tabs[(2u * (q - 1u) + 1u) * GTZ_KEYS + key] - 1u : 0xFFFFFFFFu;
+        if (GTZ_CANDS > 2) cand[2] = q ? s->tabs[(2u * (q - 1u)) * GTZ_KEYS + key] : 0xFFFFFFFFu;
+        if (GTZ_CANDS > 3) cand[3] = q > 1u ? s->tabs[(2u * (q - 2u) + 1u) * GTZ_KEYS + key] - 1u : 0xFFFFFFFFu;
         const uint32_t room = c.j1 - j;
-        const bool ok0 = c0 < g, ok1 = c1 < g;
-        const uint32_t s0 = ok0 ? c0 : g, s1 = ok1 ? c1 : g; // a disabled candidate reads its own position
-        const uint32_t w0 = gtz_window(s->cells, s0), w1 = gtz_window(s->cells, s1);
-        uint32_t n0 = (w0 ^ dw) ? (uint32_t)__builtin_ctz(w0 ^ dw) >> 1 : 16u;
-        uint32_t n1 = (w1 ^ dw) ? (uint32_t)__builtin_ctz(w1 ^ dw) >> 1 : 16u;
-        uint32_t lim0 = room, lim1 = room, d0 = 4u * (g - s0), d1 = 4u * (g - s1);
-        if ((ok0 && s0 < grow) || (ok1 && s1 < grow)) { // a source in an earlier row of the member: its own byte distance and end
+        bool ok[GTZ_CANDS], other_row = false;
+        uint32_t sg[GTZ_CANDS], n[GTZ_CANDS], lim[GTZ_CANDS], d[GTZ_CANDS];
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                const uint32_t sg = t ? s1 : s0;
-                if (!(t ? ok1 : ok0) || sg >= grow) continue;
+        for (int t = 0; t < (int)GTZ_CANDS; ++t) {
+            ok[t] = cand[t] < g;
+            if (t == 2 && ok[2] && cand[2] == cand[1]) ok[2] = false; // one occurrence in that quarter: same position twice
+            sg[t] = ok[t] ? cand[t] : g; // a disabled candidate reads its own position
+            other_row |= ok[t] && sg[t] < grow;
+        }
+#pragma unroll
+        for (int t = 0; t < (int)GTZ_CANDS; ++t) {
+            const uint32_t xw0 = gtz_window(s->cells, sg[t]) ^ dw;
+            n[t] = xw0 ? (uint32_t)__builtin_ctz(xw0) >> 1 : 16u;
+            lim[t] = room;
+            d[t] = 4u * (g - sg[t]);
+        }
+        if (other_row) { // a source in an earlier row of the member: its own byte distance and end
+#pragma unroll
+            for (int t = 0; t < (int)GTZ_CANDS; ++t) {
+                if (!ok[t] || sg[t] >= grow) continue;
                 uint32_t r = i;
-                while (16u * s->gw[r] > sg) --r;
-                const uint32_t ks = sg - 16u * s->gw[r] + 16u * s->kw0[r];
-                const uint32_t d = (uint32_t)(cs + 4 * (int32_t)(64u * c64 + j) - (s->cs[r] + 4 * (int32_t)ks));
-                const uint32_t lim = min(room, s->ke[r] - ks);
-                if (t) { d1 = d; lim1 = lim; } else { d0 = d; lim0 = lim; }
+                while (16u * s->gw[r] > sg[t]) --r;
+                const uint32_t ks = sg[t] - 16u * s->gw[r] + 16u * s->kw0[r];
+                d[t] = (uint32_t)(cs + 4 * (int32_t)(64u * c64 + j) - (s->cs[r] + 4 * (int32_t)ks));
+                lim[t] = min(room, s->ke[r] - ks);
             }
         }
-        // longer than one window: keep comparing (rare except in sparse rows)
-        if (ok0 && n0 == 16u)
-            while (n0 < lim0) {
-                const uint32_t x = c.window(j + n0) ^ gtz_window(s->cells, s0 + n0);
-                if (x) { n0 += (uint32_t)__builtin_ctz(x) >> 1; break; }
-                n0 += 16u;
-            }
-        if (ok1 && n1 == 16u)
-            while (n1 < lim1) {
-                const uint32_t x = c.window(j + n1) ^ gtz_window(s->cells, s1 + n1);
-                if (x) { n1 += (uint32_t)__builtin_ctz(x) >> 1; break; }
-                n1 += 16u;
-            }
-        n0 = (ok0 && d0 <= 32768u) ? min(n0, lim0) : 0u;
-        n1 = (ok1 && d1 <= 32768u) ? min(n1, lim1) : 0u;
-        const bool first = n0 > n1 || (n0 == n1 && d0 <= d1);
-        const uint32_t f = first ? n0 : n1, dbytes = first ? d0 : d1;
+        uint32_t f = 0, dbytes = 0;
+#pragma unroll
+        for (int t = 0; t < (int)GTZ_CANDS; ++t) {
+            // longer than one window: keep comparing (rare except in sparse rows)
+            if (ok[t] && n[t] == 16u)
+                while (n[t] < lim[t]) {
+                    const uint32_t x = c.window(j + n[t]) ^ gtz_window(s->cells, sg[t] + n[t]);
+                    if (x) { n[t] += (uint32_t)__builtin_ctz(x) >> 1; break; }
+                    n[t] += 16u;
+                }
+            const uint32_t nt = (ok[t] && d[t] <= 32768u) ? min(n[t], lim[t]) : 0u;
+            if (nt > f || (nt == f && nt && d[t] < dbytes)) { f = nt; dbytes = d[t]; } // ties: the nearer one
+        }
         bool take = f >= GTZ_KEY_CELLS;
         if (take) {
             const uint32_t a = 2u * j, b = 2u * (j + f);
