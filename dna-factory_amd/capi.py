@@ -35,7 +35,7 @@ SYMBOLS = [
     "dnaf_format_prefixes", "dnaf_bgzf_compress", "dnaf_read_bgzf", "dnaf_last_bgzf_ms",
     "dnaf_bgzf_tables_from_histogram", "dnaf_gtz_tables_from_histogram", "dnaf_set_mt_state", "dnaf_mt_jump_host", "dnaf_mt_characteristic_polynomial",
     "dnaf_fetch_bgzf", "dnaf_fetch_text", "dnaf_read_text_range", "dnaf_format_snps_json", "dnaf_parse_snps_json",
-    "dnaf_allele_counts",
+    "dnaf_allele_counts", "dnaf_export_bed", "dnaf_read_bed",
 ]
 
 
@@ -97,6 +97,8 @@ def _load():
         "dnaf_fetch_text": (ci, [vp, vp, vp]),
         "dnaf_read_text_range": (ci, [vp, u64, u64, vp]),
         "dnaf_allele_counts": (ci, [vp, vp, u64]),
+        "dnaf_export_bed": (ci, [vp, vp]),
+        "dnaf_read_bed": (ci, [vp, vp, u64, vp]),
         "dnaf_format_snps_json": (ci, [u64, vp, vp, u32, vp, vp, u32, vp, u32, vp, vp, vp, vp, vp, u64, vp]),
         "dnaf_parse_snps_json": (ci, [vp, u64, u64, vp, vp, u32, vp, vp, u32, vp, vp, vp]),
         "dnaf_mt_jump_host": (ci, [vp, u64, vp]),
@@ -339,6 +341,14 @@ class Context:
         flags = (BGZF_REUSE_TABLES if reuse_tables else 0) | (BGZF_TEXT_DOMAIN if text_domain else 0)
         self._check(lib.dnaf_bgzf_compress(self._h, flags, ctypes.byref(n)))
         return n.value
+
+    def export_bed(self):
+        """PLINK .bed rows (without the 3 magic bytes) of the last packed matrix: u8[n_rows][ceil(S/4)]."""
+        n = ctypes.c_uint64(0)
+        self._check(lib.dnaf_export_bed(self._h, ctypes.byref(n)))
+        buf = np.empty(max(n.value, 1), dtype=np.uint8)
+        self._check(lib.dnaf_read_bed(self._h, ptr(buf), n.value, ctypes.byref(n)))
+        return buf[: n.value]
 
     def read_bgzf(self, n_bytes):
         buf = np.empty(max(n_bytes, 1), dtype=np.uint8)

@@ -57,6 +57,9 @@ def parse_cmd_args(args):
     p.add_argument("--host-bgzf", action="store_true",
                    help="compress on the host with zlib at level -z (like the reference) instead of the on-GPU BGZF "
                         "encoder, which ignores -z")
+    p.add_argument("--plink", action="store_true",
+                   help="also write population.bed and population.bim (PLINK 1 binary genotypes made on the GPU from the "
+                        "2-bit matrix; population.fam is the matching .fam), so PLINK need not convert the VCF")
     p.add_argument("--compat-chunk-restart", action="store_true",
                    help="restart the random stream at every 1M-SNP work chunk like the reference does "
                         "(pop_factory.py:402-411; only matters from 2M SNPs up)")
@@ -84,7 +87,8 @@ def reference_chunks(n):
     return split_ranges(n, int(n / 1000000) or 1)
 
 
-def _generate_shard(device, seed, rng, mt_state, st, tb, row_lo, row_hi, rng_row_lo, tile_rows, sink, progress, host_bgzf):
+def _generate_shard(device, seed, rng, mt_state, st, tb, row_lo, row_hi, rng_row_lo, tile_rows, sink, progress, host_bgzf,
+                    bed_sink=None):
     """Rows [row_lo, row_hi) of the table on one GPU -> the BGZF sink, in order.  By default the text is
     compressed on the GPU and only BGZF members cross PCIe; with host_bgzf the text is copied out and
     compressed by the sink's zlib workers."""
@@ -102,7 +106,9 @@ def _generate_shard(device, seed, rng, mt_state, st, tb, row_lo, row_hi, rng_row
         pending = None  # the sink drains tile k on the writer thread while the GPU produces tile k+1
         for b in range(0, n, tile_rows):
             m = min(tile_rows, n - b)
-            gen.ctx.generate(b, m, capi.OUT_TEXT if host_bgzf else capi.OUT_TEXT | capi.OUT_PACKED)
+            gen.ctx.generate(b, m, capi.OUT_TEXT if host_bgzf and bed_sink is None else capi.OUT_TEXT | capi.OUT_PACKED)
+            if bed_sink is not None:
+                bed_sink.write(gen.ctx.export_bed())  # .bed rows of this tile, straight from the packed matrix
             if host_bgzf:
                 view, put = gen.ctx.fetch_text(), sink.write
             else:
@@ -118,8 +124,11 @@ def _generate_shard(device, seed, rng, mt_state, st, tb, row_lo, row_hi, rng_row
             pending.result()
 
 
+BED_MAGIC = bytes([0x6C, 0x1B, 0x01])  # PLINK 1 .bed, SNP-major
+
+
 def write_vcf(path, header, st, tb, seed, rng, devices, compresslevel, tile_rows=0, threads=0, host_bgzf=False,
-              mt_state=None, chunk_restart=False):
+              mt_state=None, chunk_restart=False, bed_path=None):
     """population.vcf.gz = header + one body line per SNP (output_vcf_population, pop_factory.py:385-415).
     With several devices each GPU writes its contiguous SNP range to its own BGZF shard; shards are then
     concatenated (BGZF members are independent), ending with a single EOF block."""
@@ -144,10 +153,15 @@ def write_vcf(path, header, st, tb, seed, rng, devices, compresslevel, tile_rows
     # with chunk_restart the stream restarts at every reference work chunk, as the reference's does.
     units = [(lo, hi, 0) for lo, hi in reference_chunks(n)] if chunk_restart else [(0, n, 0)]
     if len(devices) == 1:
+        bed = open(bed_path, "wb") if bed_path else None
+        if bed:
+            bed.write(BED_MAGIC)
         with bgzf.BgzfWriter(path, compresslevel=compresslevel, threads=threads) as f:
             f.write(header)
             for lo, hi, r0 in units:
-                _generate_shard(devices[0], seed, rng, mt_state, st, tb, lo, hi, r0, tile_rows, f, progress, host_bgzf)
+                _generate_shard(devices[0], seed, rng, mt_state, st, tb, lo, hi, r0, tile_rows, f, progress, host_bgzf, bed)
+        if bed:
+            bed.close()
     else:
         from math import gcd
 
@@ -161,17 +175,18 @@ def write_vcf(path, header, st, tb, seed, rng, devices, compresslevel, tile_rows
             q = 156 // gcd(len(st), 156)
             bounds = [min(n, (b + q - 1) // q * q) for b in bounds[:-1]] + [n]
         shard_paths = ["%s.shard%d" % (path, g) for g in range(G)]
+        bed_shards = ["%s.shard%d" % (bed_path, g) for g in range(G)] if bed_path else []
         errors = []
 
         def run(g):
             try:
-                with open(shard_paths[g], "wb") as raw:
+                with open(shard_paths[g], "wb") as raw, open(bed_shards[g] if bed_path else os.devnull, "wb") as bed:
                     w = bgzf.BgzfWriter(fileobj=_NoClose(raw), compresslevel=compresslevel, threads=threads)
                     if g == 0:
                         w.write(header)
                     if bounds[g + 1] > bounds[g]:
                         _generate_shard(devices[g], seed, rng, mt_state, st, tb, bounds[g], bounds[g + 1], bounds[g], tile_rows, w,
-                                        progress, host_bgzf)
+                                        progress, host_bgzf, bed if bed_path else None)
                     w.flush()  # no EOF block inside a shard
                     w.close_pool()
             except BaseException as e:  # surfaced in the parent, never swallowed
@@ -194,6 +209,17 @@ def write_vcf(path, header, st, tb, seed, rng, devices, compresslevel, tile_rows
                         out.write(chunk)
                 os.remove(sp)
             out.write(bgzf.EOF_BLOCK)
+        if bed_path:
+            with open(bed_path, "wb") as out:
+                out.write(BED_MAGIC)
+                for sp in bed_shards:
+                    with open(sp, "rb") as f:
+                        while True:
+                            chunk = f.read(8 << 20)
+                            if not chunk:
+                                break
+                            out.write(chunk)
+                    os.remove(sp)
     print("Finished VCF file output. (%.1f s)" % (time.time() - t0), flush=True)
 
 
@@ -260,7 +286,9 @@ def generate_population(args):
         mt_state = (state[1], int(state[2]))
     write_vcf(outdir + "population.vcf.gz", header, st, tb, seed, args.rng, devices, args.compression_level,
               tile_rows=args.tile_rows, threads=args.threads, host_bgzf=args.host_bgzf, mt_state=mt_state,
-              chunk_restart=args.compat_chunk_restart)
+              chunk_restart=args.compat_chunk_restart, bed_path=outdir + "population.bed" if args.plink else None)
+    if args.plink:
+        pop.write_bim(tb, outdir + "population.bim")
     print("Finished Generating Population in %0.4f secs." % (time.time() - t_start), flush=True)
     return outdir
 

@@ -8,6 +8,7 @@
 #include "rowgen_kernels.hip.h"
 #include "bgzf_kernels.hip.h"
 #include "gtz_kernels.hip.h"
+#include "bed_kernels.hip.h"
 #include "mt_jump.h"
 #include "mt_kernels.hip.h"
 
@@ -106,6 +107,11 @@ struct dnaf_ctx {
     uint8_t* d_stage = nullptr;
     uint64_t stage_cap = 0;
     bool have_gtz_tables = false;
+
+    // PLINK .bed rows of the last packed matrix
+    uint8_t* d_bed = nullptr;
+    uint64_t bed_cap = 0, bed_bytes = 0;
+    bool have_bed = false;
 
     // pinned host staging for device -> host copies at PCIe rate
     void* h_pinned[2] = {nullptr, nullptr}; // alternate, so that one fetched range stays valid while the next is produced
@@ -215,6 +221,7 @@ int dnaf_destroy(dnaf_ctx* c)
     dev_free(c->d_large);
     dev_free(c->d_offsets);
     dev_free(c->d_bgzf);
+    dev_free(c->d_bed);
     dev_free(c->d_gtz_tables);
     dev_free(c->d_gtz_hist);
     dev_free(c->d_member_row);
@@ -782,6 +789,44 @@ int dnaf_allele_counts(dnaf_ctx* c, uint32_t* counts, uint64_t cap_rows)
                        (const uint32_t*)c->d_packed, (const uint32_t*)c->d_ctrl2, c->W, n, c->d_counts);
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipMemcpyAsync(counts, c->d_counts, n * 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return DNAF_OK;
+}
+
+// PLINK 1 .bed rows (SNP-major, 2 bits per sample, A1 = ALT, A2 = REF) of the last generated packed matrix.
+int dnaf_export_bed(dnaf_ctx* c, uint64_t* n_bytes)
+{
+    if (!c) return DNAF_ERR_BAD_ARG;
+    if (!c->have_output || !(c->last_what & DNAF_OUT_PACKED)) return fail(c, DNAF_ERR_STATE, "dnaf_export_bed: no packed matrix was generated");
+    c->have_bed = false;
+    const uint64_t row_bytes = ((uint64_t)c->S + 3) / 4, n = c->last_rows, total = n * row_bytes;
+    if (n_bytes) *n_bytes = total;
+    c->bed_bytes = total;
+    if (total == 0) { c->have_bed = true; return DNAF_OK; }
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (total > c->bed_cap) {
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        dev_free(c->d_bed);
+        c->bed_cap = 0;
+        HIP_TRY(c, hipMalloc((void**)&c->d_bed, total));
+        c->bed_cap = total;
+    }
+    const uint64_t words = n * c->W;
+    hipLaunchKernelGGL(dnaf::bed_kernel, dim3((uint32_t)((words + 255) / 256)), dim3(256), 0, c->stream, (const uint32_t*)c->d_packed,
+                       (const RowRec*)(c->d_recs + c->last_begin), (const uint8_t*)c->d_male_nib, c->S, c->W, c->G, n, c->d_bed);
+    HIP_TRY(c, hipGetLastError());
+    c->have_bed = true;
+    return DNAF_OK;
+}
+
+int dnaf_read_bed(dnaf_ctx* c, void* dst, uint64_t dst_cap, uint64_t* n_bytes)
+{
+    if (!c) return DNAF_ERR_BAD_ARG;
+    if (!c->have_bed) return fail(c, DNAF_ERR_STATE, "dnaf_read_bed: nothing was exported");
+    if (n_bytes) *n_bytes = c->bed_bytes;
+    if (c->bed_bytes > dst_cap || (c->bed_bytes && !dst)) return fail(c, DNAF_ERR_BAD_ARG, "dnaf_read_bed: need %llu bytes", (unsigned long long)c->bed_bytes);
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (c->bed_bytes) HIP_TRY(c, hipMemcpyAsync(dst, c->d_bed, c->bed_bytes, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return DNAF_OK;
 }

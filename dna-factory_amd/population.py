@@ -315,6 +315,20 @@ def build_samples(groups, control_size, test_size, male_odds, outdir, offset=0):
     return st
 
 
+def write_bim(tb, path):
+    """PLINK .bim for the rows of population.bed: chromosome, rs id, 0 cM, position, A1 = ALT (the first one of a
+    multi-allelic row), A2 = REF -- the allele order dnaf_export_bed codes against."""
+    chrom = np.char.decode(tb.chrom, "ascii")
+    ref = np.char.decode(tb.ref, "ascii")
+    alt = np.char.partition(np.char.decode(tb.alt, "ascii"), ",")[:, 0]
+    with open(path, "w") as f:
+        step = 200000
+        for b in range(0, len(tb), step):
+            e = min(len(tb), b + step)
+            f.write("".join("%s\trs%d\t0\t%d\t%s\t%s\n" % t for t in zip(chrom[b:e], tb.snp_id[b:e].tolist(), tb.position[b:e].tolist(),
+                                                                         alt[b:e], ref[b:e])))
+
+
 def vcf_header(person_ids, now=None):
     """gen_vcf_header, pop_factory.py:36-44."""
     now = now or datetime.now()

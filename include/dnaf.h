@@ -149,6 +149,14 @@ int dnaf_allele_counts(dnaf_ctx* ctx, uint32_t* counts, uint64_t cap_rows);
 /* Bytes [byte_begin, byte_begin + n_bytes) of the last generated text (consumers that stream a tile out in pieces). */
 int dnaf_read_text_range(dnaf_ctx* ctx, uint64_t byte_begin, uint64_t n_bytes, void* dst);
 
+/* PLINK 1 binary genotypes of the last generated packed matrix, made on the GPU: n_rows rows of
+ * ceil(S/4) bytes in .bed order (SNP-major; sample i at bits 2*(i%4) of byte i/4; with A1 = ALT and
+ * A2 = REF in the .bim: 3 = 0/0, 2 = heterozygous, 0 = 1/1, 1 = missing).  Haploid cells (males on X / Y,
+ * MT) are stored as homozygous, females on Y as missing -- what PLINK makes of the VCF the reference
+ * writes (plink_analysis.py feeds population.vcf.gz to plink).  The 3 magic bytes are the caller's. */
+int dnaf_export_bed(dnaf_ctx* ctx, uint64_t* n_bytes);
+int dnaf_read_bed(dnaf_ctx* ctx, void* dst, uint64_t dst_cap, uint64_t* n_bytes);
+
 /* Device pointers of the last generated range, for consumers that stay on
  * the GPU (valid until the next dnaf_generate / dnaf_destroy). */
 int dnaf_device_buffers(dnaf_ctx* ctx, void** d_text, uint64_t* text_bytes, void** d_packed, uint64_t* packed_words);

@@ -220,3 +220,30 @@ def test_extreme_shapes(RowGenerator, oracle, S, n_rows):
         text, off, packed = g.generate()
     bad = oracle.verify_threads(oracle.table_records(tb), sex, ctrl, doff, dids, 3, 8, text, off, packed)
     assert bad is None, "row %s differs" % bad
+
+
+@pytest.mark.parametrize("n_rows,S", [(5, 1), (9, 5), (20, 16), (33, 17), (12, 4099)])
+def test_bed_export_matches_the_text(RowGenerator, n_rows, S):
+    """dnaf_export_bed: PLINK 1 .bed rows from the packed matrix equal what the VCF text says cell by cell (A1 = ALT:
+    0/0 -> 3, one non-reference allele -> 2, two -> 0; haploid calls homozygous; '.' -> 1), including multi-allelic
+    rows (any non-reference allele counts) and every chromosome class; padding bits are zero."""
+    rs = np.random.RandomState(77 + n_rows + S)
+    snps, samples = random_case(rs, n_rows, S)
+    with RowGenerator(device=0, seed=int(rs.randint(0, 2**31))) as g:
+        g.set_samples(samples)
+        g.set_snps(snps)
+        lines = g.lines()
+        g.ctx.generate(0, n_rows, 3)
+        bed = g.ctx.export_bed().reshape(n_rows, (S + 3) // 4)
+    for j, line in enumerate(lines):
+        codes = (bed[j][:, None] >> (2 * np.arange(4))[None, :]).reshape(-1) & 3
+        assert not codes[S:].any()
+        for i, cell in enumerate(line.rstrip("\n").split("\t")[9:]):
+            if cell == ".":
+                want = 1
+            elif "/" in cell:
+                a, b = cell.split("/")
+                want = {0: 3, 1: 2, 2: 0}[(a != "0") + (b != "0")]
+            else:
+                want = 3 if cell == "0" else 0
+            assert codes[i] == want, (j, i, cell)
