@@ -877,7 +877,7 @@ int dnaf_bgzf_compress(dnaf_ctx* c, uint32_t flags, uint64_t* n_bytes)
     if (!c->have_output || !(c->last_what & DNAF_OUT_TEXT)) return fail(c, DNAF_ERR_STATE, "dnaf_bgzf_compress: no text was generated");
     if (flags & ~(DNAF_BGZF_REUSE_TABLES | DNAF_BGZF_TEXT_DOMAIN)) return fail(c, DNAF_ERR_BAD_ARG, "dnaf_bgzf_compress: flags = %u", flags);
     // members that lie in biallelic autosome rows are made from the genotype matrix when it was generated too
-    const bool gtz = (c->last_what & DNAF_OUT_PACKED) && !(flags & DNAF_BGZF_TEXT_DOMAIN) && c->S >= 2;
+    bool gtz = (c->last_what & DNAF_OUT_PACKED) && !(flags & DNAF_BGZF_TEXT_DOMAIN) && c->S >= 2;
     HIP_TRY(c, hipSetDevice(c->device));
     const uint64_t tbytes = c->h_text_off[(size_t)(c->last_begin + c->last_rows)] - c->h_text_off[(size_t)c->last_begin];
     c->have_bgzf = false;
@@ -925,6 +925,14 @@ int dnaf_bgzf_compress(dnaf_ctx* c, uint32_t flags, uint64_t* n_bytes)
     p.large_list = c->d_large;
     p.offsets = c->d_offsets;
     p.out = nullptr;
+    if (gtz && (uint64_t)nb * dnaf::GTZ_STRIDE > c->stage_cap) {
+        // staging slots of the genotype-domain members; without room for them every member is made from the text
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        dev_free(c->d_stage);
+        c->stage_cap = 0;
+        if (hipMalloc((void**)&c->d_stage, (uint64_t)nb * dnaf::GTZ_STRIDE) == hipSuccess) c->stage_cap = (uint64_t)nb * dnaf::GTZ_STRIDE;
+        else { (void)hipGetLastError(); c->d_stage = nullptr; gtz = false; }
+    }
     p.fast = gtz ? c->d_fast : nullptr;
     p.todo = nullptr;
     uint32_t n_todo = nb; // members the text-domain kernels encode
@@ -933,14 +941,6 @@ int dnaf_bgzf_compress(dnaf_ctx* c, uint32_t flags, uint64_t* n_bytes)
     if (gtz) {
         if (!c->d_gtz_tables) HIP_TRY(c, hipMalloc((void**)&c->d_gtz_tables, sizeof(dnaf::GtzTables)));
         if (!c->d_gtz_hist) HIP_TRY(c, hipMalloc((void**)&c->d_gtz_hist, dnaf::GTZ_NCLASS * dnaf::GTZ_NSYM * sizeof(uint32_t)));
-        const uint64_t want = (uint64_t)nb * dnaf::GTZ_STRIDE;
-        if (want > c->stage_cap) {
-            HIP_TRY(c, hipStreamSynchronize(c->stream));
-            dev_free(c->d_stage);
-            c->stage_cap = 0;
-            HIP_TRY(c, hipMalloc((void**)&c->d_stage, want));
-            c->stage_cap = want;
-        }
         g.recs = c->d_recs;
         g.prefix = c->d_prefix;
         g.packed = (const uint32_t*)c->d_packed;
