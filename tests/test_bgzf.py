@@ -381,3 +381,31 @@ def test_gtz_extreme_rows(capi):
         blob, _ = g.generate_bgzf()
     assert gzip.decompress(blob.tobytes()) == text.tobytes()
     assert text[:200].tobytes().count(b"1/1\t0/0\t") > 10
+
+
+@pytest.mark.gpu
+def test_bgzf_random_shapes_and_ranges(capi):
+    """Forty random combinations of sample count, table size, fixed-column width, sex mix, forced set and row range
+    (tools/bgzf_experiments/fuzz.py ran 10,000 of them): whatever the mix of encoders, the output inflates to the text."""
+    from dna_factory_amd import genome
+    from dna_factory_amd.rowgen import RowGenerator
+    from dna_factory_amd.tables import SampleTable
+
+    rs = np.random.RandomState(2026)
+    for case in range(40):
+        S = int([rs.randint(2, 40), rs.randint(900, 5000), rs.randint(5000, 40000), rs.choice([15359, 15360, 15361, 30720])][case % 4])
+        n = int(max(3, min(1500, 12e6 / (4 * S + 40))))
+        tb = genome.synthetic_snp_table(n, min_maf=float(rs.choice([0.005, 0.05, 0.3])), rs=rs)
+        if case % 3 == 0:
+            tb.snp_id = tb.snp_id * int(rs.choice([1000, 10**9])) + 3
+        flags = (rs.rand(S) <= rs.choice([0.0, 0.5, 1.0])).astype(np.uint8) | (np.arange(S) < S // 2).astype(np.uint8) * 2
+        carriers = np.sort(rs.choice(np.arange(S // 2, S), size=max(1, (S - S // 2) // 3), replace=False)).astype(np.uint32)
+        st = SampleTable(flags, [int(tb.snp_id[n // 2])], [0, len(carriers)], carriers)
+        with RowGenerator(device=0, seed=int(rs.randint(0, 2**31))) as g:
+            g.set_samples(st)
+            g.set_snps(tb)
+            b = int(rs.randint(0, n))
+            m = int(rs.randint(1, n - b + 1))
+            text, _, _ = g.generate(b, m, text=True, packed=False)
+            blob, n_text = g.generate_bgzf(b, m)
+            assert n_text == len(text) and gzip.decompress(blob.tobytes()) == text.tobytes(), (case, S, n, b, m)
