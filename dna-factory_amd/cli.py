@@ -104,21 +104,29 @@ def _generate_shard(device, seed, rng, mt_state, st, tb, row_lo, row_hi, rng_row
         q = gen.row_quantum
         tile_rows = max(q, tile_rows // q * q)
         pending = None  # the sink drains tile k on the writer thread while the GPU produces tile k+1
+        trace = os.environ.get("DNAF_TRACE_TILES")  # per-tile seconds: GPU work, device -> host copy, wait for the writer
         for b in range(0, n, tile_rows):
             m = min(tile_rows, n - b)
+            t0 = time.time()
             gen.ctx.generate(b, m, capi.OUT_TEXT if host_bgzf and bed_sink is None else capi.OUT_TEXT | capi.OUT_PACKED)
             if bed_sink is not None:
                 bed_sink.write(gen.ctx.export_bed())  # .bed rows of this tile, straight from the packed matrix
             if host_bgzf:
+                gen.ctx.sync()
+                t1 = time.time()
                 view, put = gen.ctx.fetch_text(), sink.write
             else:
                 gen.ctx.bgzf_compress(reuse_tables=b > 0)
+                t1 = time.time()
                 view, put = gen.ctx.fetch_bgzf(), sink.write_members
+            t2 = time.time()
             # the library alternates two pinned staging buffers: tile k's stays valid through the fetch of tile k+1,
             # so its write only has to finish before tile k+2 is fetched
             if pending is not None:
                 pending.result()
             pending = writer.submit(put, view)
+            if trace:
+                print("tile %d: gpu %.3f s, copy %.3f s (%.0f MB), writer wait %.3f s" % (b // tile_rows, t1 - t0, t2 - t1, len(view) / 1e6, time.time() - t2), flush=True)
             progress(m)
         if pending is not None:
             pending.result()
