@@ -250,3 +250,21 @@ def test_plink_bed_matches_the_vcf(tmp_path):
             assert codes[i] == want, (j, i, cell)
             seen.add((f[0] in ("X", "Y", "MT"), cell))
     assert {c for _, c in seen} >= {"0/0", "0/1", "1/1", "0", "1", "."}
+
+
+@pytest.mark.gpu
+def test_two_shards_give_the_same_vcf_and_bed(tmp_path):
+    """--devices 0,0: two contexts write their SNP ranges to shard files that are appended in the kernel
+    (copy_file_range); VCF text and .bed bytes equal the one-device run's."""
+    import gzip
+
+    base = [sys.executable, os.path.join(REPO, "pop_factory.py"), "-s", "90", "-c", "80", "-x", "5000", "-f", "0.01", "--seed", "9", "--plink"]
+    one, two = tmp_path / "one", tmp_path / "two"
+    for out, extra in ((one, []), (two, ["--devices", "0,0", "--tile-rows", "700"])):
+        rc = subprocess.run(base + ["--outdir", str(out)] + extra, capture_output=True, text=True)
+        assert rc.returncode == 0, rc.stderr[-2000:]
+    body = lambda p: [l for l in gzip.open(p / "population.vcf.gz", "rt").read().splitlines() if not l.startswith("##filedate")]
+    assert body(one) == body(two)
+    assert (one / "population.bed").read_bytes() == (two / "population.bed").read_bytes()
+    assert (one / "population.bim").read_bytes() == (two / "population.bim").read_bytes()
+    assert not [f for f in os.listdir(two) if "shard" in f]
