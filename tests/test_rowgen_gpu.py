@@ -247,3 +247,31 @@ def test_bed_export_matches_the_text(RowGenerator, n_rows, S):
             else:
                 want = 3 if cell == "0" else 0
             assert codes[i] == want, (j, i, cell)
+
+
+def test_reserve_output_probes_placements_and_results_stay_exact(RowGenerator, oracle):
+    """dnaf_reserve_output with a table loaded and more than 1 GiB of text times the kernel on up to four placements
+    of the two output buffers and keeps the fastest; whatever it keeps, the rows are the oracle's."""
+    from dna_factory_amd.tables import SampleTable, SnpTable
+
+    S, n = 20000, 14000
+    rs = np.random.RandomState(31)
+    flags = (rs.rand(S) <= 0.5).astype(np.uint8) | (np.arange(S) < S // 2).astype(np.uint8) * 2
+    st = SampleTable(flags)
+    cum = np.ones((n, 4))
+    cum[:, 0] = 1 - 0.005 * rs.randint(2, 100, n)
+    tb = SnpTable(np.arange(1, n + 1), np.full(n, b"4", dtype="S2"), np.arange(n) * 7 + 1, np.full(n, b"G", dtype="S1"),
+                  np.full(n, b"A", dtype="S1"), np.full(n, 2, np.uint8), cum)
+    sex, ctrl, doff, dids = oracle.sample_arrays_from_table(st.flags, st.forced_ids, st.carrier_off, st.carrier_idx)
+    with RowGenerator(device=0, seed=44) as g:
+        g.set_samples(st)
+        g.set_snps(tb)
+        assert g.ctx.text_bytes(0, n) > 1 << 30
+        g.ctx.reserve_output(g.ctx.text_bytes(0, n), n * g.words_per_row)
+        g.ctx.generate(0, n, 3)
+        off = g.ctx.row_offsets(0, n)
+        for b in (0, n - 40):
+            text = g.ctx.read_text_range(int(off[b]), int(off[b + 40] - off[b]))
+            want, _, want_packed = oracle.generate(oracle.table_records(tb, b, b + 40), sex, ctrl, doff, dids, seed=44, rng_row0=b)
+            assert text.tobytes() == want
+        assert np.array_equal(g.ctx.read_packed(n, g.words_per_row)[n - 40:], want_packed)
