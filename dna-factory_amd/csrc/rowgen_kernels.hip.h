@@ -90,6 +90,10 @@ __device__ __forceinline__ void store_unaligned(uint8_t* dst, const void* src)
     __builtin_memcpy(dst, src, N); // byte-aligned destination: hardware unaligned global stores
 }
 
+// pointers into LDS carry their address space, so that accesses through a struct member stay ds_* instructions
+#define LDS_PTR(T) T __attribute__((address_space(3)))*
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4))); // plain vector: loads through an LDS pointer
+
 struct SegCtx {
     uint32_t t0, t1, t2;   // thresholds
     uint32_t r_lo, r_hi;   // RNG row
@@ -100,8 +104,8 @@ struct SegCtx {
     const uint8_t* frow;   // forced nibbles of the row's slot or nullptr
     const uint8_t* male_nib;
     const uint32_t* xoff;
-    const uint4* lut;      // LDS: the 16 text bytes of 4 biallelic diploid cells for each packed byte
-    uint8_t* stage;        // LDS: this wave's packed bytes of the segment (PK_STAGE bytes), written out in 16-byte pieces
+    const LDS_PTR(u32x4_t) lut; // the 16 text bytes of 4 biallelic diploid cells for each packed byte
+    LDS_PTR(uint8_t) stage;     // this wave's packed bytes of the segment (PK_STAGE bytes), written out in 16-byte pieces
 };
 constexpr uint32_t PK_STAGE = 2048; // packed bytes a wave can stage = groups per segment at 32 trips
 
@@ -336,11 +340,24 @@ __device__ __forceinline__ void row_segment(const SegCtx& c, uint32_t cls, uint3
         // The packed bytes of the segment are staged in LDS and leave as whole 16-byte stores after the loop instead
         // of one byte store per lane and trip (64 B per wave, half a cache line): 3 % faster.
         const bool staged = PACKED && g_end - g_begin <= PK_STAGE;
+        // whole trips of complete groups first: no lane is out of range and none holds the row's last sample
+        for (; gb + 64u <= g_fast; gb += 64u) {
+            const uint32_t g = gb + lane;
+            const uint32_t pk = biallelic_code(c, g);
+            if (TEXT) {
+                const u32x4_t w = c.lut[pk];
+                store_unaligned<16>(c.cells + 16ull * g, &w);
+            }
+            if (PACKED) {
+                if (staged) c.stage[g - g_begin] = (uint8_t)pk;
+                else c.prow[g] = (uint8_t)pk;
+            }
+        }
         for (; gb < g_end; gb += 64u) {
             const uint32_t g = gb + lane;
             if (g < g_end) {
                 uint32_t pk = biallelic_code(c, g);
-                uint4 w = make_uint4(0, 0, 0, 0);
+                u32x4_t w = {0, 0, 0, 0};
                 if (TEXT) w = c.lut[pk];
                 const uint32_t d0 = w.x, d1 = w.y, d2 = w.z, d3 = w.w;
                 if (g < g_fast) {
@@ -369,7 +386,7 @@ __device__ __forceinline__ void row_segment(const SegCtx& c, uint32_t cls, uint3
             const uint32_t n = g_end - g_begin;
             uint8_t* dst = c.prow + g_begin;
             for (uint32_t o = 16u * lane; o + 16u <= n; o += 1024u) {
-                const uint4 v = *reinterpret_cast<const uint4*>(c.stage + o);
+                const u32x4_t v = *reinterpret_cast<const LDS_PTR(u32x4_t)>(c.stage + o);
                 store_unaligned<16>(dst + o, &v);
             }
             if (lane < (n & 15u)) dst[(n & ~15u) + lane] = c.stage[(n & ~15u) + lane];
@@ -399,12 +416,13 @@ template <bool TEXT, bool PACKED>
 __global__ __launch_bounds__(256) void rowgen_kernel(const GenParams p)
 {
     // text of 4 biallelic diploid cells by packed byte: entry pk = "a0/b0\ta1/b1\ta2/b2\ta3/b3\t"
-    __shared__ uint4 cell_lut[256];
+    __shared__ u32x4_t cell_lut[256];
     __shared__ __attribute__((aligned(16))) uint8_t pk_stage[4][PK_STAGE];
     if (TEXT) {
         const uint32_t t = threadIdx.x;
-        cell_lut[t] = make_uint4(CELL00 + (t & 1u) + ((t & 2u) << 15), CELL00 + ((t >> 2) & 1u) + ((t & 8u) << 13),
-                                 CELL00 + ((t >> 4) & 1u) + ((t & 32u) << 11), CELL00 + ((t >> 6) & 1u) + ((t & 128u) << 9));
+        const u32x4_t e = {CELL00 + (t & 1u) + ((t & 2u) << 15), CELL00 + ((t >> 2) & 1u) + ((t & 8u) << 13),
+                           CELL00 + ((t >> 4) & 1u) + ((t & 32u) << 11), CELL00 + ((t >> 6) & 1u) + ((t & 128u) << 9)};
+        cell_lut[t] = e;
         __syncthreads();
     }
     const uint32_t lane = threadIdx.x & 63u;
@@ -438,8 +456,8 @@ __global__ __launch_bounds__(256) void rowgen_kernel(const GenParams p)
     c.prow = p.packed + row_local * (uint64_t)p.W * 4u;
     c.frow = rec.slot >= 0 ? p.forced + (uint64_t)rec.slot * p.G : nullptr;
     c.male_nib = p.male_nib;
-    c.lut = cell_lut;
-    c.stage = pk_stage[threadIdx.x >> 6];
+    c.lut = (const LDS_PTR(u32x4_t))cell_lut;
+    c.stage = (LDS_PTR(uint8_t))pk_stage[threadIdx.x >> 6];
     c.xoff = p.xoff;
     if (rec.n_alleles > 2) row_segment<TEXT, PACKED, true>(c, rec.cls, g_begin, g_end, g_stop, lane);
     else row_segment<TEXT, PACKED, false>(c, rec.cls, g_begin, g_end, g_stop, lane);
