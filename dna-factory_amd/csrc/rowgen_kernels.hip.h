@@ -168,16 +168,23 @@ __device__ __forceinline__ uint32_t shift_in_gt(uint32_t pk, uint32_t u, uint32_
     asm("v_cmp_lt_u32 vcc, %2, %1\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(pk) : "v"(u), "s"(t) : "vcc");
     return pk;
 }
+// the first draw of a byte: 0 + 0 + (u > t), no register to clear
+__device__ __forceinline__ uint32_t first_gt(uint32_t u, uint32_t t)
+{
+    uint32_t pk;
+    asm("v_cmp_lt_u32 vcc, %2, %1\n\tv_addc_co_u32 %0, vcc, 0, 0, vcc" : "=v"(pk) : "v"(u), "s"(t) : "vcc");
+    return pk;
+}
 
 // The packed byte of group g on a biallelic row straight from its 8 draws: bit 2k = first allele of sample 4g+k,
 // bit 2k+1 = its second allele, forced genotypes applied.  One compare and one add-with-carry per draw; the
 // text of the four cells is then one 16-byte LDS look-up (SegCtx::lut) instead of selects, ors and shifts.
-__device__ __forceinline__ uint32_t biallelic_code(const SegCtx& c, uint32_t g)
+// c0 = 2 g is the Philox counter of the group's first block (callers that walk a row keep it in a register).
+__device__ __forceinline__ uint32_t biallelic_code(const SegCtx& c, uint32_t c0)
 {
-    const uint4 x = philox4x32_10(2u * g, 0u, c.r_lo, c.r_hi, c.k0, c.k1);
-    const uint4 y = philox4x32_10(2u * g + 1u, 0u, c.r_lo, c.r_hi, c.k0, c.k1);
-    uint32_t pk = 0;
-    pk = shift_in_gt(pk, y.w, c.t0);
+    const uint4 x = philox4x32_10(c0, 0u, c.r_lo, c.r_hi, c.k0, c.k1);
+    const uint4 y = philox4x32_10(c0 | 1u, 0u, c.r_lo, c.r_hi, c.k0, c.k1);
+    uint32_t pk = first_gt(y.w, c.t0);
     pk = shift_in_gt(pk, y.z, c.t0);
     pk = shift_in_gt(pk, y.y, c.t0);
     pk = shift_in_gt(pk, y.x, c.t0);
@@ -186,7 +193,7 @@ __device__ __forceinline__ uint32_t biallelic_code(const SegCtx& c, uint32_t g)
     pk = shift_in_gt(pk, x.y, c.t0);
     pk = shift_in_gt(pk, x.x, c.t0);
     if (c.frow) { // wave-uniform; forced = "1/1", pop_factory.py:495-499
-        uint32_t f = c.frow[g] & 0xFu;
+        uint32_t f = c.frow[c0 >> 1] & 0xFu;
         f = (f | (f << 2)) & 0x33u;
         f = (f | (f << 1)) & 0x55u;
         pk |= f * 3u;
@@ -341,22 +348,27 @@ __device__ __forceinline__ void row_segment(const SegCtx& c, uint32_t cls, uint3
         // of one byte store per lane and trip (64 B per wave, half a cache line): 3 % faster.
         const bool staged = PACKED && g_end - g_begin <= PK_STAGE;
         // whole trips of complete groups first: no lane is out of range and none holds the row's last sample
-        for (; gb + 64u <= g_fast; gb += 64u) {
-            const uint32_t g = gb + lane;
-            const uint32_t pk = biallelic_code(c, g);
-            if (TEXT) {
-                const u32x4_t w = c.lut[pk];
-                store_unaligned<16>(c.cells + 16ull * g, &w);
-            }
-            if (PACKED) {
-                if (staged) c.stage[g - g_begin] = (uint8_t)pk;
-                else c.prow[g] = (uint8_t)pk;
+        // (counter, text pointer and staging pointer advance by constants: no per-trip address arithmetic from g)
+        {
+            uint32_t c0 = 2u * (gb + lane);
+            uint8_t* tp = c.cells + 16ull * (gb + lane);
+            LDS_PTR(uint8_t) sp = c.stage + (gb + lane - g_begin);
+            for (; gb + 64u <= g_fast; gb += 64u, c0 += 128u, tp += 1024, sp += 64) {
+                const uint32_t pk = biallelic_code(c, c0);
+                if (TEXT) {
+                    const u32x4_t w = c.lut[pk];
+                    store_unaligned<16>(tp, &w);
+                }
+                if (PACKED) {
+                    if (staged) *sp = (uint8_t)pk;
+                    else c.prow[c0 >> 1] = (uint8_t)pk;
+                }
             }
         }
         for (; gb < g_end; gb += 64u) {
             const uint32_t g = gb + lane;
             if (g < g_end) {
-                uint32_t pk = biallelic_code(c, g);
+                uint32_t pk = biallelic_code(c, 2u * g);
                 u32x4_t w = {0, 0, 0, 0};
                 if (TEXT) w = c.lut[pk];
                 const uint32_t d0 = w.x, d1 = w.y, d2 = w.z, d3 = w.w;
