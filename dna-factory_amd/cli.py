@@ -68,9 +68,16 @@ def parse_cmd_args(args):
     return p.parse_args(args)
 
 
-def _auto_tile_rows(n_samples, n_rows):
+def _auto_tile_rows(n_samples, n_rows, rng="philox"):
+    """Rows per launch: about 512 MiB of text.  In MT19937 mode a wave owns 156 / gcd(S, 156) whole rows of the
+    sequential stream, so a tile must hold a few thousand waves' worth of rows to fill the chip (up to 16 GiB of text)."""
     per_row = 64 + 4 * max(n_samples, 1)
-    return max(1, min(max(n_rows, 1), (512 << 20) // per_row))
+    rows = (512 << 20) // per_row
+    if rng == "mt19937" and n_samples:
+        from math import gcd
+
+        rows = max(rows, min(4096 * (156 // gcd(n_samples, 156)), (16 << 30) // per_row))
+    return max(1, min(max(n_rows, 1), rows))
 
 
 def split_ranges(n, chunks):
@@ -145,7 +152,7 @@ def write_vcf(path, header, st, tb, seed, rng, devices, compresslevel, tile_rows
     n = len(tb)
     if n == 0:
         raise Exception("No SNPs to Process! Exiting.")  # pop_factory.py:395-396
-    tile_rows = tile_rows or _auto_tile_rows(len(st), n)
+    tile_rows = tile_rows or _auto_tile_rows(len(st), n, rng)
     threads = threads or max(1, min(16, (os.cpu_count() or 4) // max(1, len(devices))))
     done = [0]
     lock = threading.Lock()
