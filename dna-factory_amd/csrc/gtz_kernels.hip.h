@@ -48,7 +48,8 @@ constexpr uint32_t GTZ_STRIDE = 16384;    // staging slot of a member
 constexpr uint32_t GTZ_OUT_WORDS = GTZ_STRIDE / 4;
 constexpr uint32_t GTZ_MIN_BREAKS = 3;    // an LZ77 match must replace at least this many literal bytes
 constexpr uint32_t GTZ_CANDS = 4;         // source candidates looked at per break (2..4)
-static_assert(2 * GTZ_SEGS * GTZ_KEYS >= GTZ_OUT_WORDS, "the member image reuses the key tables");
+static_assert(2 * GTZ_SEGS * GTZ_KEYS * 2 == GTZ_OUT_WORDS * 4, "the member image reuses the key tables");
+static_assert(GTZ_MAX_CHUNKS * GTZ_MAX_FAR >= 2 * GTZ_KEYS, "the match lists lend their space to the table build");
 
 struct GtzParams {
     const RowRec* recs;      // [table rows]
@@ -86,7 +87,10 @@ __global__ __launch_bounds__(256) void gtz_locate(const GtzParams p)
 }
 
 struct GtzShared {
-    uint32_t tabs[2 * GTZ_SEGS * GTZ_KEYS]; // [seg][0 = earliest, 1 = latest + 1][key]; later the member image
+    union {
+        uint16_t tab16[2 * GTZ_SEGS * GTZ_KEYS]; // [quarter][0 = earliest (0xFFFF: none), 1 = latest + 1 (0: none)][key]
+        uint32_t image[GTZ_OUT_WORDS];           // later the member image
+    };
     uint32_t cells[GTZ_CELL_WORDS + 4];
     uint32_t far[GTZ_MAX_CHUNKS * GTZ_MAX_FAR]; // cell in chunk | cells << 6 | distance in bytes << 13
     uint32_t codes[256 + 256 + 32];             // lit, len, dist code tables; the symbol histogram in gtz_encode<true>
@@ -230,7 +234,7 @@ struct GtzEmit {
         acc |= (uint64_t)v << nacc;
         nacc += n;
         if (nacc >= 32u) {
-            atomicOr(&s->tabs[word], (uint32_t)acc);
+            atomicOr(&s->image[word], (uint32_t)acc);
             ++word;
             acc >>= 32;
             nacc -= 32u;
@@ -248,7 +252,7 @@ struct GtzEmit {
     }
     __device__ __forceinline__ void flush()
     {
-        if (nacc) atomicOr(&s->tabs[word], (uint32_t)acc);
+        if (nacc) atomicOr(&s->image[word], (uint32_t)acc);
     }
 };
 
@@ -364,7 +368,6 @@ __global__ __launch_bounds__(GTZ_THREADS) void gtz_encode(const GtzParams p)
         }
     }
     if (tid < 4) s->cells[s->gw[nr] + tid] = 0;
-    for (uint32_t t = tid; t < 2 * GTZ_SEGS * GTZ_KEYS; t += GTZ_THREADS) s->tabs[t] = ((t / GTZ_KEYS) & 1u) ? 0u : 0xFFFFFFFFu;
     if (HIST) {
         for (uint32_t t = tid; t < GTZ_NSYM; t += GTZ_THREADS) s->hist()[t] = 0;
     } else {
@@ -376,25 +379,40 @@ __global__ __launch_bounds__(GTZ_THREADS) void gtz_encode(const GtzParams p)
         if (tid < GTZ_CHUNK_CELLS) { s->crc_unit_a[tid] = p.tables->crc_unit_a[tid]; s->crc_unit_b[tid] = p.tables->crc_unit_b[tid]; }
     }
     __syncthreads();
-    for (uint32_t i = 0; i < nr; ++i) {
-        const uint32_t kb = s->kb[i], ke = s->ke[i];
-        if (ke - kb < GTZ_KEY_CELLS) continue;
-        const uint32_t gbase = 16u * s->gw[i] - 16u * s->kw0[i];
-        // Lanes hold consecutive positions.  Of a run of equal keys only its first position can be the
-        // earliest and only its last the latest, so the others stay away from the table: long stretches of
-        // "0/0" would otherwise send every lane's atomic to one LDS address.
-        for (uint32_t kk = kb; kk + GTZ_KEY_CELLS <= ke; kk += GTZ_THREADS) {
-            const uint32_t k = kk + tid;
-            const bool live = k + GTZ_KEY_CELLS <= ke;
-            const uint32_t g = gbase + k;
-            const uint32_t slot = live ? (min(g >> GTZ_SEG_SHIFT, GTZ_SEGS - 1u) << 11) | (gtz_window(s->cells, g) & (GTZ_KEYS - 1u)) : 0xFFFFFFFFu;
-            const uint32_t before = __shfl_up(slot, 1, 64), after = __shfl_down(slot, 1, 64);
-            const uint32_t lane = tid & 63u;
-            if (live && (lane == 0u || before != slot)) atomicMin(&s->tabs[(slot >> 11) * 2u * GTZ_KEYS + (slot & (GTZ_KEYS - 1u))], g);
-            if (live && (lane == 63u || after != slot)) atomicMax(&s->tabs[((slot >> 11) * 2u + 1u) * GTZ_KEYS + (slot & (GTZ_KEYS - 1u))], g + 1u);
+    // Key tables, one quarter of the g space at a time: earliest / latest position of every key with 32-bit LDS
+    // atomics in a scratch area (the match lists' space, not yet in use), then narrowed to 16 bits -- the tables
+    // that stay are 16 KB instead of 32, which is what lets a fourth workgroup share the CU.
+    {
+        uint32_t* scr = s->far; // [0, KEYS): earliest, [KEYS, 2 KEYS): latest + 1
+        for (uint32_t q = 0; q < GTZ_SEGS; ++q) {
+            for (uint32_t t = tid; t < 2 * GTZ_KEYS; t += GTZ_THREADS) scr[t] = t < GTZ_KEYS ? 0xFFFFFFFFu : 0u;
+            __syncthreads();
+            const uint32_t qlo = q << GTZ_SEG_SHIFT, qhi = q + 1u == GTZ_SEGS ? 0xFFFFFFFFu : (q + 1u) << GTZ_SEG_SHIFT;
+            for (uint32_t i = 0; i < nr; ++i) {
+                const uint32_t kb = s->kb[i], ke = s->ke[i];
+                if (ke - kb < GTZ_KEY_CELLS) continue;
+                const uint32_t gbase = 16u * s->gw[i] - 16u * s->kw0[i];
+                // positions of this row whose g lies in the quarter
+                const uint32_t g_first = gbase + kb, g_end = gbase + ke - GTZ_KEY_CELLS + 1u;
+                const uint32_t lo = max(g_first, qlo), hi = min(g_end, qhi);
+                // Lanes hold consecutive positions.  Of a run of equal keys only its first position can be the
+                // earliest and only its last the latest, so the others stay away from the table: long stretches
+                // of "0/0" would otherwise send every lane's atomic to one LDS address.
+                for (uint32_t gg = lo; gg < hi; gg += GTZ_THREADS) {
+                    const uint32_t g = gg + tid;
+                    const bool live = g < hi;
+                    const uint32_t key = live ? gtz_window(s->cells, g) & (GTZ_KEYS - 1u) : 0xFFFFFFFFu;
+                    const uint32_t before = __shfl_up(key, 1, 64), after = __shfl_down(key, 1, 64);
+                    const uint32_t lane = tid & 63u;
+                    if (live && (lane == 0u || before != key)) atomicMin(&scr[key], g);
+                    if (live && (lane == 63u || after != key)) atomicMax(&scr[GTZ_KEYS + key], g + 1u);
+                }
+            }
+            __syncthreads();
+            for (uint32_t t = tid; t < 2 * GTZ_KEYS; t += GTZ_THREADS) s->tab16[2u * q * GTZ_KEYS + t] = (uint16_t)min(scr[t], 0xFFFFu);
+            __syncthreads();
         }
     }
-    __syncthreads();
 
     // code lengths of the four literals a cell is made of, one byte each
     const uint32_t lit_bits = HIST ? 0u : (s->lit()['0'] & 31u) | ((s->lit()['1'] & 31u) << 8) | ((s->lit()['/'] & 31u) << 16) | ((s->lit()['\t'] & 31u) << 24);
@@ -513,23 +531,23 @@ __global__ __launch_bounds__(GTZ_THREADS) void gtz_encode(const GtzParams p)
 
     // ---- pass 2: the member image in LDS ----
     const uint32_t image_words = (size + 3u) >> 2;
-    for (uint32_t t = tid; t < image_words; t += GTZ_THREADS) s->tabs[t] = 0;
+    for (uint32_t t = tid; t < image_words; t += GTZ_THREADS) s->image[t] = 0;
     __syncthreads();
     if (tid < 18) {
         const uint8_t h[18] = {0x1F, 0x8B, 8, 4, 0, 0, 0, 0, 0, 0xFF, 6, 0, 0x42, 0x43, 2, 0,
                                (uint8_t)((size - 1u) & 0xFFu), (uint8_t)((size - 1u) >> 8)};
-        atomicOr(&s->tabs[tid >> 2], (uint32_t)h[tid] << (8u * (tid & 3u)));
+        atomicOr(&s->image[tid >> 2], (uint32_t)h[tid] << (8u * (tid & 3u)));
     }
     if (tid < 8) {
         const uint32_t v = tid < 4 ? member_crc : N;
         const uint32_t at = 18u + body + tid;
-        atomicOr(&s->tabs[at >> 2], ((v >> (8u * (tid & 3u))) & 0xFFu) << (8u * (at & 3u)));
+        atomicOr(&s->image[at >> 2], ((v >> (8u * (tid & 3u))) & 0xFFu) << (8u * (at & 3u)));
     }
     constexpr uint32_t BIT0 = 18u * 8u; // deflate bits start behind the gzip header
     if (tid < (hdr_bits + 31u) / 32u) {
         const uint32_t v = ct->hdr[tid];
-        atomicOr(&s->tabs[(BIT0 >> 5) + tid], v << (BIT0 & 31u));
-        atomicOr(&s->tabs[(BIT0 >> 5) + tid + 1u], v >> (32u - (BIT0 & 31u)));
+        atomicOr(&s->image[(BIT0 >> 5) + tid], v << (BIT0 & 31u));
+        atomicOr(&s->image[(BIT0 >> 5) + tid + 1u], v >> (32u - (BIT0 & 31u)));
     }
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
@@ -541,7 +559,7 @@ __global__ __launch_bounds__(GTZ_THREADS) void gtz_encode(const GtzParams p)
             for (int32_t pos = s->span_lo[i]; pos < s->span_hi[i]; ++pos) e.lit(gtz_text_byte(p, s, m_row, i, pos));
             e.flush();
         } else {
-            GtzBitEmit e{s->tabs, s->len(), s->dist(), {s->lit()['0'], s->lit()['1'], s->lit()['/'], s->lit()['\t']}, 0, start & 31u, start >> 5};
+            GtzBitEmit e{s->image, s->len(), s->dist(), {s->lit()['0'], s->lit()['1'], s->lit()['/'], s->lit()['\t']}, 0, start & 31u, start >> 5};
             gtz_emit_tokens(ch[u], tks[u], it_far[u], e);
             e.flush();
         }
@@ -556,7 +574,7 @@ __global__ __launch_bounds__(GTZ_THREADS) void gtz_encode(const GtzParams p)
     }
     __syncthreads();
     uint4* dst = reinterpret_cast<uint4*>(p.stage + (uint64_t)m * GTZ_STRIDE);
-    const uint4* src = reinterpret_cast<const uint4*>(s->tabs);
+    const uint4* src = reinterpret_cast<const uint4*>(s->image);
     for (uint32_t t = tid; t < (size + 15u) >> 4; t += GTZ_THREADS) dst[t] = src[t];
 }
 

@@ -263,10 +263,10 @@ __device__ __forceinline__ void gtz_find_matches(GtzShared* s, uint32_t i, uint3
         const uint32_t q = min(g >> GTZ_SEG_SHIFT, GTZ_SEGS - 1u);
         // candidates: earliest in this quarter, latest / earliest in the one before, latest two back
         uint32_t cand[GTZ_CANDS];
-        cand[0] = s->tabs[(2u * q) * GTZ_KEYS + key];
-        cand[1] = q ? s->tabs[(2u * (q - 1u) + 1u) * GTZ_KEYS + key] - 1u : 0xFFFFFFFFu;
-        if (GTZ_CANDS > 2) cand[2] = q ? s->tabs[(2u * (q - 1u)) * GTZ_KEYS + key] : 0xFFFFFFFFu;
-        if (GTZ_CANDS > 3) cand[3] = q > 1u ? s->tabs[(2u * (q - 2u) + 1u) * GTZ_KEYS + key] - 1u : 0xFFFFFFFFu;
+        cand[0] = s->tab16[(2u * q) * GTZ_KEYS + key]; // 0xFFFF (none) is never below g
+        cand[1] = q ? (uint32_t)s->tab16[(2u * (q - 1u) + 1u) * GTZ_KEYS + key] - 1u : 0xFFFFFFFFu;
+        if (GTZ_CANDS > 2) cand[2] = q ? (uint32_t)s->tab16[(2u * (q - 1u)) * GTZ_KEYS + key] : 0xFFFFFFFFu;
+        if (GTZ_CANDS > 3) cand[3] = q > 1u ? (uint32_t)s->tab16[(2u * (q - 2u) + 1u) * GTZ_KEYS + key] - 1u : 0xFFFFFFFFu;
         const uint32_t room = c.j1 - j;
         bool ok[GTZ_CANDS], other_row = false;
         uint32_t sg[GTZ_CANDS], n[GTZ_CANDS], lim[GTZ_CANDS], d[GTZ_CANDS];
