@@ -42,7 +42,7 @@ constexpr uint32_t GTZ_SEG_SHIFT = 12;
 constexpr uint32_t GTZ_MAX_ROWS = 16;     // rows overlapping one member
 constexpr uint32_t GTZ_MAX_CHUNKS = 240 + 2 * GTZ_MAX_ROWS;
 constexpr uint32_t GTZ_MAX_ITEMS = 2 * GTZ_THREADS; // chunks + literal spans, two per thread
-constexpr uint32_t GTZ_MAX_FAR = 10;      // LZ77 matches recorded per chunk
+constexpr uint32_t GTZ_MAX_FAR = 12;      // LZ77 matches recorded per chunk (64 cells / 5)
 constexpr uint32_t GTZ_CELL_WORDS = BGZF_IN / 64 + 2 * GTZ_MAX_ROWS + 8;
 constexpr uint32_t GTZ_STRIDE = 16384;    // staging slot of a member
 constexpr uint32_t GTZ_OUT_WORDS = GTZ_STRIDE / 4;
