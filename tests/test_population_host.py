@@ -146,3 +146,21 @@ def test_random_choice_replay_leaves_python_random_in_step(pop):
         got = pop._replay_random_choice3(count)
         assert [int(x) for x in got] == want
         assert random.getstate() == after
+
+
+def test_shard_files_are_appended_in_order(tmp_path):
+    """cli._append_file (kernel-side copy where available) leaves the destination positioned at its end, so that
+    header || shard 0 || shard 1 || EOF block comes out in order."""
+    from dna_factory_amd import cli
+
+    rs = np.random.RandomState(3)
+    parts = [rs.randint(0, 256, n).astype(np.uint8).tobytes() for n in (5 << 20, 1, 0, 70000)]
+    for k, blob in enumerate(parts):
+        (tmp_path / ("shard%d" % k)).write_bytes(blob)
+    out_path = tmp_path / "joined"
+    with open(out_path, "wb") as out:
+        out.write(b"header")
+        for k in range(len(parts)):
+            cli._append_file(out, str(tmp_path / ("shard%d" % k)))
+        out.write(b"EOF")
+    assert out_path.read_bytes() == b"header" + b"".join(parts) + b"EOF"
