@@ -275,3 +275,16 @@ def test_reserve_output_probes_placements_and_results_stay_exact(RowGenerator, o
             want, _, want_packed = oracle.generate(oracle.table_records(tb, b, b + 40), sex, ctrl, doff, dids, seed=44, rng_row0=b)
             assert text.tobytes() == want
         assert np.array_equal(g.ctx.read_packed(n, g.words_per_row)[n - 40:], want_packed)
+
+
+def test_hip_matches_oracle_fuzz(RowGenerator, oracle):
+    """Eighty random cases around the kernel's internal boundaries: one trip (<= 256 samples), the whole-trip loop vs
+    its tail, one segment = 2048 groups = 8192 samples, two and three segments; every chromosome class, forced cells,
+    1-4 alleles (helpers.random_case).  Text, offsets and packed matrix are the oracle's."""
+    rs = np.random.RandomState(4242)
+    pools = [range(1, 70), range(250, 262), range(1000, 1100), range(8186, 8200), range(16378, 16392), range(20000, 20004)]
+    for case in range(80):
+        S = int(rs.choice(list(pools[case % len(pools)])))
+        n_rows = int(rs.randint(1, 10 if S > 4000 else 40))
+        snps, samples = random_case(rs, n_rows, S)
+        check_case(RowGenerator, oracle, snps, samples, seed=int(rs.randint(0, 2**31)), rng_row0=int(rs.randint(0, 1000)))
