@@ -57,6 +57,25 @@ __global__ __launch_bounds__(256) void k_store16(uint8_t* dst, uint64_t bytes_pe
     }
 }
 
+// text-stream shape of the row kernel: "rows" of row_bytes (any value, so every row has its own byte alignment),
+// each cut into segments of seg_steps KiB, one wave per segment; the first pfx bytes of a row are skipped
+__global__ __launch_bounds__(256) void k_store_rows(uint8_t* dst, uint64_t row_bytes, uint64_t n_rows, uint32_t nseg, uint32_t seg_steps, uint32_t pfx)
+{
+    const uint32_t lane = threadIdx.x & 63;
+    const uint64_t item = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const uint64_t row = item / nseg;
+    const uint32_t seg = (uint32_t)(item % nseg);
+    if (row >= n_rows) return;
+    const uint32_t steps = (uint32_t)((row_bytes - pfx) / 1024);
+    const uint32_t s0 = seg * seg_steps, s1 = s0 + seg_steps < steps ? s0 + seg_steps : steps;
+    uint8_t* p = dst + row * row_bytes + pfx + lane * 16 + (uint64_t)s0 * 1024;
+    uint32_t v[4] = {0x092F3030u, 0x092F3031u, 0x092F3130u, 0x092F3131u};
+    for (uint32_t s = s0; s < s1; ++s, p += 1024) {
+        v[0] += lane;
+        __builtin_memcpy(p, v, 16);
+    }
+}
+
 typedef uint32_t u32x4_a1 __attribute__((ext_vector_type(4), aligned(1)));
 // same as k_store16 with non-temporal stores (global_store_dwordx4 ... nt)
 __global__ __launch_bounds__(256) void k_store16_nt(uint8_t* dst, uint64_t bytes_per_wave, uint32_t m)
@@ -132,6 +151,21 @@ int main()
     // ---- store rate vs misalignment ----
     const uint64_t total = 16ull << 30; // 16 GiB written per launch
     uint8_t* d_buf; CK(hipMalloc(&d_buf, total + 4096));
+    for (uint64_t row_bytes : {81920ull, 80037ull, 80000ull}) {
+        const uint64_t n_rows = total / row_bytes;
+        for (uint32_t seg_steps : {32u, 80u}) {
+            for (uint32_t pfx : {0u, 37u}) {
+                const uint32_t steps = (uint32_t)((row_bytes - pfx) / 1024), nseg = (steps + seg_steps - 1) / seg_steps;
+                for (int rep = 0; rep < 3; ++rep) {
+                    CK(hipEventRecord(e0));
+                    hipLaunchKernelGGL(k_store_rows, dim3((uint32_t)((n_rows * nseg + 3) / 4)), dim3(256), 0, 0, d_buf, row_bytes, n_rows, nseg, seg_steps, pfx);
+                    CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms, e0, e1));
+                }
+                printf("rows of %llu B, %u KiB per wave, first %u B skipped: %.3f ms  %.1f GB/s\n", (unsigned long long)row_bytes, seg_steps, pfx, ms,
+                       (double)n_rows * steps * 1024 / (ms * 1e-3) / 1e9);
+            }
+        }
+    }
     for (uint64_t bpw : {32768ull, 1ull << 20}) {
         const uint64_t waves = total / bpw;
         const uint32_t blocks = (uint32_t)(waves / 4);
