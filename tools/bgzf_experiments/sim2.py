@@ -20,8 +20,6 @@ def parse_member(codes, C, k, minfar, mode="latest"):
     def add(h, s): h[s] = h.get(s, 0) + 1
     # keys
     key = np.zeros(n, np.int64)
-    for j in range(k): key[: n - j] |= codes[j:].astype(np.int64)[: n - j] << (2 * j) if j == 0 else (codes[j:].astype(np.int64) << (2 * j))[: n - j] if False else 0
-    key = np.zeros(n, np.int64)
     for j in range(k):
         key[: n - k + 1] |= codes[j: n - k + 1 + j].astype(np.int64) << (2 * j)
     valid = np.zeros(n, bool); valid[: n - k + 1] = True
