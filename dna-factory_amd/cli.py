@@ -291,10 +291,22 @@ def generate_population(args):
         raise SystemExit("-l (load from the RefSNP database) is not supported: the database path is outside this "
                          "generator's scope; use simulated SNPs or --snps_file")
     tb = pop.sort_snp_table(tb)
+    snps_writer = None
     if not args.snps_file:
-        t = time.time()
-        pop.write_snps_file(tb, outdir + "snps.json.gz")
-        print("Time to write snps file %0.4f seconds" % (time.time() - t), flush=True)
+        # snps.json.gz only reads the table: it is written on a side thread while the deleterious picks, the sample
+        # files and the VCF are made (its formatter and gzip workers release the GIL)
+        snps_error = []
+
+        def write_snps():
+            try:
+                t = time.time()
+                pop.write_snps_file(tb, outdir + "snps.json.gz")
+                print("Time to write snps file %0.4f seconds" % (time.time() - t), flush=True)
+            except BaseException as e:  # re-raised after the join below
+                snps_error.append(e)
+
+        snps_writer = threading.Thread(target=write_snps)
+        snps_writer.start()
 
     if args.deleterious_file:
         groups = pop.load_deleterious_json(args.deleterious_file, int_keys=not args.compat_deleterious_file_bug)
@@ -319,6 +331,10 @@ def generate_population(args):
               chunk_restart=args.compat_chunk_restart, bed_path=outdir + "population.bed" if args.plink else None)
     if args.plink:
         pop.write_bim(tb, outdir + "population.bim")
+    if snps_writer is not None:
+        snps_writer.join()
+        if snps_error:
+            raise snps_error[0]
     print("Finished Generating Population in %0.4f secs." % (time.time() - t_start), flush=True)
     return outdir
 
