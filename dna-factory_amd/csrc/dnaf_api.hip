@@ -556,10 +556,12 @@ int dnaf_reserve_output(dnaf_ctx* c, uint64_t text_bytes, uint64_t packed_words)
 }
 
 // ---- numpy-compatible MT19937 mode (mt_kernels.hip.h) ----
+// One jumper per process, built once: contexts of several host threads (multi-GPU runs) reach this concurrently,
+// and C++ guarantees that the initialisation of a function-local static runs exactly once and is complete before
+// any caller proceeds.
 static dnaf::MtJumper& mt_jumper()
 {
-    static dnaf::MtJumper j;
-    j.init();
+    static dnaf::MtJumper j = [] { dnaf::MtJumper t; t.init(); return t; }();
     return j;
 }
 

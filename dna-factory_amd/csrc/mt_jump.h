@@ -104,16 +104,20 @@ struct MtJumper {
     // r(x) = r(x)^2 mod phi
     void square_mod(MtPoly* r) const
     {
-        static uint16_t spread[256];
-        static bool have = false;
-        if (!have) {
-            for (int b = 0; b < 256; ++b) {
-                uint16_t v = 0;
-                for (int i = 0; i < 8; ++i) v |= (uint16_t)(((b >> i) & 1) << (2 * i));
-                spread[b] = v;
+        // bit-spreading table, built once (thread-safe static initialisation)
+        struct Spread {
+            uint16_t v[256];
+            Spread()
+            {
+                for (int b = 0; b < 256; ++b) {
+                    uint16_t x = 0;
+                    for (int i = 0; i < 8; ++i) x |= (uint16_t)(((b >> i) & 1) << (2 * i));
+                    v[b] = x;
+                }
             }
-            have = true;
-        }
+        };
+        static const Spread spread_table;
+        const uint16_t* spread = spread_table.v;
         uint64_t t[2 * MT_POLY_WORDS];
         for (int w = 0; w < MT_POLY_WORDS; ++w) {
             const uint64_t v = r->w[w];

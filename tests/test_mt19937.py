@@ -1,9 +1,12 @@
 """numpy-compatible MT19937 mode: jump-ahead machinery (CPU) and the GPU path against the UNMODIFIED reference
 (fixtures `lines_mt`: pop_factory.py:471-513 after numpy.random.seed(k), no patching) and the oracle's MT mode."""
 import ctypes
+import os
 
 import numpy as np
 import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 from helpers import golden_inputs, golden_names, load_golden, random_case
 
@@ -186,3 +189,44 @@ def test_dropin_write_vcf_snps_with_reference_shaped_objects(RowGenerator, oracl
     with RowGenerator(device=0, rng="mt19937", mt_state=state[1:3]) as g:
         assert g.write_vcf_snps(fam, ref_snps, sink) == 90
     assert sink.getvalue() == want
+
+
+@pytest.mark.gpu
+def test_mt_mode_first_use_from_several_threads(tmp_path):
+    """Multi-GPU runs create one context per host thread; the jump-ahead machinery (characteristic polynomial, found
+    once per process) must come up safely when several threads need it first at the same moment.  Fresh processes,
+    four threads each, all results equal to the single-threaded answer."""
+    import subprocess
+    import sys
+
+    code = r'''
+import sys, threading
+sys.path.insert(0, %r)
+import numpy as np
+import __graft_entry__ as ge
+ge.build()
+from dna_factory_amd.rowgen import RowGenerator
+from dna_factory_amd.tables import SampleTable, SnpTable
+S, n = 52, 600
+flags = (np.arange(S) %% 2).astype(np.uint8) | (np.arange(S) < S // 2).astype(np.uint8) * 2
+cum = np.ones((n, 4)); cum[:, 0] = 1 - 0.005 * (1 + np.arange(n) %% 90)
+tb = SnpTable(np.arange(1, n + 1), np.full(n, b"5", dtype="S2"), np.arange(n) + 1, np.full(n, b"A", dtype="S1"),
+              np.full(n, b"C", dtype="S1"), np.full(n, 2, np.uint8), cum)
+out = [None] * 4
+def work(k):
+    with RowGenerator(device=0, seed=4321, rng="mt19937") as g:
+        g.set_samples(SampleTable(flags)); g.set_snps(tb)
+        q = g.row_quantum
+        parts = [g.generate(b, min(150 // q * q, n - b))[0].tobytes() for b in range(0, n, 150 // q * q)]
+        out[k] = b"".join(parts)
+ths = [threading.Thread(target=work, args=(k,)) for k in range(4)]
+[t.start() for t in ths]; [t.join() for t in ths]
+with RowGenerator(device=0, seed=4321, rng="mt19937") as g:
+    g.set_samples(SampleTable(flags)); g.set_snps(tb)
+    ref = g.generate()[0].tobytes()
+assert all(o == ref for o in out), [o == ref for o in out]
+print("ok")
+''' % REPO
+    for _ in range(3):
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True)
+        assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stderr[-2000:]
