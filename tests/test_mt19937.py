@@ -200,7 +200,7 @@ def test_mt_mode_first_use_from_several_threads(tmp_path):
     import sys
 
     code = r'''
-import sys, threading
+import sys, threading, time
 sys.path.insert(0, %r)
 import numpy as np
 import __graft_entry__ as ge
@@ -213,10 +213,13 @@ cum = np.ones((n, 4)); cum[:, 0] = 1 - 0.005 * (1 + np.arange(n) %% 90)
 tb = SnpTable(np.arange(1, n + 1), np.full(n, b"5", dtype="S2"), np.arange(n) + 1, np.full(n, b"A", dtype="S1"),
               np.full(n, b"C", dtype="S1"), np.full(n, 2, np.uint8), cum)
 out = [None] * 4
+gate = threading.Barrier(4)
 def work(k):
     with RowGenerator(device=0, seed=4321, rng="mt19937") as g:
         g.set_samples(SampleTable(flags)); g.set_snps(tb)
         q = g.row_quantum
+        gate.wait()  # the first generate of the process builds the jump machinery: the four arrive a few ms apart
+        time.sleep(0.004 * k)
         parts = [g.generate(b, min(150 // q * q, n - b))[0].tobytes() for b in range(0, n, 150 // q * q)]
         out[k] = b"".join(parts)
 ths = [threading.Thread(target=work, args=(k,)) for k in range(4)]
