@@ -124,9 +124,10 @@ int dnaf_row_offsets(const dnaf_ctx* ctx, uint64_t row_begin, uint64_t n_rows, u
 int dnaf_generate(dnaf_ctx* ctx, uint64_t row_begin, uint64_t n_rows, uint32_t what);
 /* Size the output buffers ahead of time so that no later dnaf_generate has to grow them.  With a
  * table loaded, Philox mode and more than 1 GiB of text, the call also chooses where the two buffers
- * live: it times the row kernel on up to four allocations and keeps the fastest (the two write
- * streams run 7 % slower on some physical placements); this can take a few
- * seconds of hipMalloc.  DNAF_NO_PLACEMENT_PROBE=1 in the environment turns the search off. */
+ * live: it times the row kernel on up to eight allocations of the packed matrix (and, rarely, two
+ * of the text) and keeps the fastest -- the kernel runs 7 % slower on some physical placements of
+ * the matrix, DESIGN.md section 5.  Usually 0.1 s, a few seconds when the text has to move too.
+ * DNAF_NO_PLACEMENT_PROBE=1 in the environment turns the search off. */
 int dnaf_reserve_output(dnaf_ctx* ctx, uint64_t text_bytes, uint64_t packed_words);
 int dnaf_sync(dnaf_ctx* ctx);
 
