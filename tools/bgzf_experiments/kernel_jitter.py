@@ -14,6 +14,7 @@ tb = genome.synthetic_snp_table(n, min_maf=0.01, rs=rs)
 flags = (rs.rand(S) <= 0.5).astype(np.uint8) | (np.arange(S) < S // 2).astype(np.uint8) * 2
 with RowGenerator(device=0, seed=12345) as g:
     g.set_samples(SampleTable(flags)); g.set_snps(tb)
+    g.ctx.reserve_output(g.ctx.text_bytes(0, n), n * g.words_per_row)  # includes the placement search
     ms = []
     for i in range(int(sys.argv[1]) if len(sys.argv) > 1 else 60):
         g.ctx.generate(0, n, capi.OUT_TEXT | capi.OUT_PACKED)
