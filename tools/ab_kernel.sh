@@ -7,12 +7,13 @@ set -e
 REV=${1:-HEAD}
 python dna-factory_amd/build.py > /dev/null
 cp dna-factory_amd/csrc/libdnaf_hip.so tools/ab_new.so
-git stash -q
+DIRTY=0; git diff --quiet -- dna-factory_amd/csrc || DIRTY=1
+[ $DIRTY = 1 ] && git stash -q -- dna-factory_amd/csrc
 git checkout -q "$REV" -- dna-factory_amd/csrc
 python dna-factory_amd/build.py > /dev/null
 cp dna-factory_amd/csrc/libdnaf_hip.so tools/ab_base.so
 git checkout -q HEAD -- dna-factory_amd/csrc
-git stash pop -q
+[ $DIRTY = 1 ] && git stash pop -q
 python dna-factory_amd/build.py > /dev/null
 /usr/local/graft/bin/gpurun --timeout 900 -- 'cd /tmp && export TMPDIR=/tmp && R=$GRAFT_REPO_ROOT; for v in base new base new; do cp $R/tools/ab_$v.so $R/dna-factory_amd/csrc/libdnaf_hip.so; rocprofv3 --pmc SQ_INSTS_VALU GRBM_GUI_ACTIVE --output-format csv -d $R/gpurun_out/ab_$v.$RANDOM -o v -- python3 $R/tools/bgzf_experiments/kernel_jitter.py 10 > /dev/null 2>&1; done' > /dev/null 2>&1
 python - <<'PY'
