@@ -75,6 +75,26 @@ __device__ __forceinline__ uint4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_
     return make_uint4(c0, c1, c2, c3);
 }
 
+// The same block when the first round's product M0 * c0 is already known.  Callers that walk a row compute it
+// as one multiply-add from a running counter: M0 * (c0 + d) = M0 * c0 + d * M0, with d * M0 a constant.
+__device__ __forceinline__ uint4 philox4x32_10_p0(uint64_t p0_first, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
+                                                  uint32_t k1)
+{
+    uint32_t c0 = 0;
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = r == 0 ? p0_first : (uint64_t)PHILOX_M0 * c0;
+        const uint64_t p1 = (uint64_t)PHILOX_M1 * c2;
+        c0 = __builtin_amdgcn_bitop3_b32((uint32_t)(p1 >> 32), c1, k0, 0x96);
+        c1 = (uint32_t)p1;
+        c2 = __builtin_amdgcn_bitop3_b32((uint32_t)(p0 >> 32), c3, k1, 0x96);
+        c3 = (uint32_t)p0;
+        k0 += PHILOX_W0;
+        k1 += PHILOX_W1;
+    }
+    return make_uint4(c0, c1, c2, c3);
+}
+
 // SNPTuples.pick_allele_index (pop_factory.py:92-95) on integer thresholds:
 // roll = u * 2^-32, `cum >= roll`  <=>  u <= floor(cum * 2^32).
 template <bool MULTI>
@@ -179,11 +199,14 @@ __device__ __forceinline__ uint32_t first_gt(uint32_t u, uint32_t t)
 // The packed byte of group g on a biallelic row straight from its 8 draws: bit 2k = first allele of sample 4g+k,
 // bit 2k+1 = its second allele, forced genotypes applied.  One compare and one add-with-carry per draw; the
 // text of the four cells is then one 16-byte LDS look-up (SegCtx::lut) instead of selects, ors and shifts.
-// c0 = 2 g is the Philox counter of the group's first block (callers that walk a row keep it in a register).
+// c0 = 2 g is the Philox counter of the group's first block (callers that walk a row keep it in a register);
+// D = a constant number of groups ahead of c0's (the second trip of an unrolled pair): the four first-round
+// products are multiply-adds of the one counter, M0 * (c0 + 2 D + j) = M0 * c0 + (2 D + j) * M0.
+template <uint32_t D = 0>
 __device__ __forceinline__ uint32_t biallelic_code(const SegCtx& c, uint32_t c0)
 {
-    const uint4 x = philox4x32_10(c0, 0u, c.r_lo, c.r_hi, c.k0, c.k1);
-    const uint4 y = philox4x32_10(c0 | 1u, 0u, c.r_lo, c.r_hi, c.k0, c.k1);
+    const uint4 x = philox4x32_10_p0((uint64_t)PHILOX_M0 * c0 + (uint64_t)PHILOX_M0 * (2u * D), 0u, c.r_lo, c.r_hi, c.k0, c.k1);
+    const uint4 y = philox4x32_10_p0((uint64_t)PHILOX_M0 * c0 + (uint64_t)PHILOX_M0 * (2u * D + 1u), 0u, c.r_lo, c.r_hi, c.k0, c.k1);
     uint32_t pk = first_gt(y.w, c.t0);
     pk = shift_in_gt(pk, y.z, c.t0);
     pk = shift_in_gt(pk, y.y, c.t0);
@@ -193,7 +216,7 @@ __device__ __forceinline__ uint32_t biallelic_code(const SegCtx& c, uint32_t c0)
     pk = shift_in_gt(pk, x.y, c.t0);
     pk = shift_in_gt(pk, x.x, c.t0);
     if (c.frow) { // wave-uniform; forced = "1/1", pop_factory.py:495-499
-        uint32_t f = c.frow[c0 >> 1] & 0xFu;
+        uint32_t f = c.frow[(c0 >> 1) + D] & 0xFu;
         f = (f | (f << 2)) & 0x33u;
         f = (f | (f << 1)) & 0x55u;
         pk |= f * 3u;
@@ -353,6 +376,18 @@ __device__ __forceinline__ void row_segment(const SegCtx& c, uint32_t cls, uint3
             uint32_t c0 = 2u * (gb + lane);
             uint8_t* tp = c.cells + 16ull * (gb + lane);
             LDS_PTR(uint8_t) sp = c.stage + (gb + lane - g_begin);
+            for (; gb + 128u <= g_fast; gb += 128u, c0 += 256u, tp += 2048, sp += 128) { // two trips per pass
+                const uint32_t pk0 = biallelic_code<0>(c, c0), pk1 = biallelic_code<64>(c, c0);
+                if (TEXT) {
+                    const u32x4_t w0 = c.lut[pk0], w1 = c.lut[pk1];
+                    store_unaligned<16>(tp, &w0);
+                    store_unaligned<16>(tp + 1024, &w1);
+                }
+                if (PACKED) {
+                    if (staged) { sp[0] = (uint8_t)pk0; sp[64] = (uint8_t)pk1; }
+                    else { c.prow[c0 >> 1] = (uint8_t)pk0; c.prow[(c0 >> 1) + 64u] = (uint8_t)pk1; }
+                }
+            }
             for (; gb + 64u <= g_fast; gb += 64u, c0 += 128u, tp += 1024, sp += 64) {
                 const uint32_t pk = biallelic_code(c, c0);
                 if (TEXT) {
