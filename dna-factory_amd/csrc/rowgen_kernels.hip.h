@@ -376,22 +376,27 @@ __device__ __forceinline__ void row_segment(const SegCtx& c, uint32_t cls, uint3
             uint32_t c0 = 2u * (gb + lane);
             uint8_t* tp = c.cells + 16ull * (gb + lane);
             LDS_PTR(uint8_t) sp = c.stage + (gb + lane - g_begin);
-            u32x4_t w0 = {0, 0, 0, 0}, w1 = {0, 0, 0, 0}; // cells looked up one pass ago, stored while the next look-up flies
-            uint8_t* wp = nullptr;
-            for (; gb + 128u <= g_fast; gb += 128u, c0 += 256u, tp += 2048, sp += 128) { // two trips per pass
-                const uint32_t pk0 = biallelic_code<0>(c, c0), pk1 = biallelic_code<64>(c, c0);
-                if (TEXT) {
-                    if (wp) { store_unaligned<16>(wp, &w0); store_unaligned<16>(wp + 1024, &w1); }
-                    w0 = c.lut[pk0];
-                    w1 = c.lut[pk1];
-                    wp = tp;
-                }
-                if (PACKED) {
-                    if (staged) { sp[0] = (uint8_t)pk0; sp[64] = (uint8_t)pk1; }
-                    else { c.prow[c0 >> 1] = (uint8_t)pk0; c.prow[(c0 >> 1) + 64u] = (uint8_t)pk1; }
-                }
+            // Two trips per pass, software-pipelined: the cells looked up in one pass are stored in the next, so the
+            // LDS read flies under the following Philox rounds (the stores address the previous pass through tp).
+            if (gb + 128u <= g_fast) {
+                u32x4_t w0 = {0, 0, 0, 0}, w1 = {0, 0, 0, 0};
+                auto pass = [&](bool first) {
+                    const uint32_t pk0 = biallelic_code<0>(c, c0), pk1 = biallelic_code<64>(c, c0);
+                    if (TEXT) {
+                        if (!first) { store_unaligned<16>(tp - 2048, &w0); store_unaligned<16>(tp - 1024, &w1); }
+                        w0 = c.lut[pk0];
+                        w1 = c.lut[pk1];
+                    }
+                    if (PACKED) {
+                        if (staged) { sp[0] = (uint8_t)pk0; sp[64] = (uint8_t)pk1; }
+                        else { c.prow[c0 >> 1] = (uint8_t)pk0; c.prow[(c0 >> 1) + 64u] = (uint8_t)pk1; }
+                    }
+                    gb += 128u; c0 += 256u; tp += 2048; sp += 128;
+                };
+                pass(true);
+                while (gb + 128u <= g_fast) pass(false);
+                if (TEXT) { store_unaligned<16>(tp - 2048, &w0); store_unaligned<16>(tp - 1024, &w1); }
             }
-            if (TEXT && wp) { store_unaligned<16>(wp, &w0); store_unaligned<16>(wp + 1024, &w1); }
             for (; gb + 64u <= g_fast; gb += 64u, c0 += 128u, tp += 1024, sp += 64) {
                 const uint32_t pk = biallelic_code(c, c0);
                 if (TEXT) {
