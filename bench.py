@@ -265,7 +265,7 @@ def main():
                        "outputs": a.what, "rng": "philox4x32-10" if a.rng == "philox" else "mt19937 (numpy legacy)", "seed": a.seed, "table_seed": a.table_seed,
                        "sharding": "SNP-range per GPU, no collective"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "frac": achieved / HBM_PEAK_GBS, "frac_of_measured_copy_6290_GBs": achieved / 6290.0, "traffic": traffic,
                          "bytes_per_launch": bytes_per_launch, "kernel_ms_mean": mean_kernel_s * 1e3,
                          "launches_timed": n_rec, "kernel": "rowgen_kernel" if a.rng == "philox" else "mt_rowgen_kernel (+ mt_jump_kernel)",
                          "draws_per_s": 2.0 * S * a.tile_rows / mean_kernel_s},
