@@ -6,7 +6,28 @@ import subprocess
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB = os.path.join(CSRC, "libdnaf_hip.so")
 SOURCES = ["dnaf_api.hip"]
-DEPS = ["dnaf_api.hip", "rowgen_kernels.hip.h", os.path.join("..", "..", "include", "dnaf.h")]
+STAMP = LIB + ".srchash"
+
+
+def dep_files():
+    """Every file the library is compiled from: all of csrc/*.hip, csrc/*.h and the public header."""
+    import glob
+
+    files = sorted(glob.glob(os.path.join(CSRC, "*.hip")) + glob.glob(os.path.join(CSRC, "*.h")))
+    files.append(os.path.normpath(os.path.join(CSRC, "..", "..", "include", "dnaf.h")))
+    return files
+
+
+def source_hash():
+    """SHA-256 over the contents of dep_files(): what the built library is stamped with."""
+    import hashlib
+
+    h = hashlib.sha256()
+    for f in dep_files():
+        h.update(os.path.basename(f).encode() + b"\0")
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
 
 
 def hipcc_path():
@@ -17,10 +38,12 @@ def hipcc_path():
 
 
 def is_stale():
-    if not os.path.exists(LIB):
+    """True when the .so is missing or was built from other sources than the ones in the tree (content hash,
+    so a library that travelled to another box with fresh mtimes is still recognised)."""
+    if not os.path.exists(LIB) or not os.path.exists(STAMP):
         return True
-    t = os.path.getmtime(LIB)
-    return any(os.path.getmtime(os.path.join(CSRC, d)) > t for d in DEPS)
+    with open(STAMP) as fh:
+        return fh.read().strip() != source_hash()
 
 
 def build_library(force=False, verbose=False):
@@ -30,6 +53,8 @@ def build_library(force=False, verbose=False):
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd, cwd=CSRC)
+    with open(STAMP, "w") as fh:
+        fh.write(source_hash() + "\n")
     return LIB
 
 

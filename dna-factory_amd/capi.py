@@ -63,6 +63,16 @@ def _load():
         raise ImportError(
             "HIP library %s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH)
+    if "DNAF_LIB" not in os.environ:
+        # the .so is git-ignored but travels to the GPU box: refuse one that was built from other sources
+        import importlib.util
+
+        spec = importlib.util.spec_from_file_location("_dnaf_build", os.path.join(os.path.dirname(_CSRC), "build.py"))
+        bld = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(bld)
+        if bld.is_stale():
+            raise ImportError("HIP library %s is stale (csrc/ or include/dnaf.h changed since it was built): rebuild "
+                              "with `python -c 'import __graft_entry__ as g; g.build()'`" % LIB_PATH)
     lib = ctypes.CDLL(LIB_PATH)
     u64, u32, vp, ci = ctypes.c_uint64, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_int
     sig = {

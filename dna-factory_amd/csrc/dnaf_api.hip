@@ -700,6 +700,7 @@ static int generate_mt(dnaf_ctx* c, uint64_t row_begin, uint64_t n_rows, uint32_
     p.forced = c->d_forced;
     p.text = c->d_text;
     p.packed = c->d_packed;
+    p.packed_pitch = (uint64_t)c->W * 4u;
     p.text_base = c->h_text_off[(size_t)row_begin];
     p.row_begin = row_begin;
     p.n_rows = n_rows;
@@ -752,6 +753,7 @@ int dnaf_generate(dnaf_ctx* c, uint64_t row_begin, uint64_t n_rows, uint32_t wha
     p.forced = c->d_forced;
     p.text = c->d_text;
     p.packed = c->d_packed;
+    p.packed_pitch = (uint64_t)c->W * 4u;
     p.text_base = c->h_text_off[(size_t)row_begin];
     p.row_begin = row_begin;
     p.n_rows = n_rows;

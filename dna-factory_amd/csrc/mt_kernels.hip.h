@@ -172,7 +172,7 @@ __global__ __launch_bounds__(64) void mt_rowgen_kernel(const MtGenParams mp)
             if (S == 0 && lane == 0) row_text[rec.prefix_len] = 0x0A;
         }
         uint8_t* cells = row_text + rec.prefix_len;
-        uint8_t* prow = p.packed + row_local * (uint64_t)p.W * 4u;
+        uint8_t* prow = p.packed + row_local * p.packed_pitch;
         const uint8_t* frow = rec.slot >= 0 ? p.forced + (uint64_t)rec.slot * G : nullptr;
         const uint32_t cls = rec.cls;
         uint32_t consumed = 0; // words of this row consumed so far

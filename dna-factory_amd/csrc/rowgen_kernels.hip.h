@@ -42,7 +42,8 @@ struct GenParams {
     const uint32_t* xoff;      // [G+1] byte offset of group g's cells in an X row
     const uint8_t* forced;     // [n_slots][G] bit k = sample 4g+k carries the slot's SNP
     uint8_t* text;             // output text of this call (row_begin's first byte at text[0])
-    uint8_t* packed;           // output [n_rows][4*W] bytes
+    uint8_t* packed;           // output [n_rows][4*W] bytes, row j at packed + j * packed_pitch
+    uint64_t packed_pitch;     // bytes between packed rows (4*W for the ABI's dense matrix)
     uint64_t text_base;        // recs[row_begin].text_off
     uint64_t row_begin;        // first table row of this call
     uint64_t n_rows;
@@ -509,7 +510,7 @@ __global__ __launch_bounds__(256) void rowgen_kernel(const GenParams p)
     c.k0 = p.key0; c.k1 = p.key1;
     c.S = p.S; c.G = p.G;
     c.cells = row_text + rec.prefix_len;
-    c.prow = p.packed + row_local * (uint64_t)p.W * 4u;
+    c.prow = p.packed + row_local * p.packed_pitch;
     c.frow = rec.slot >= 0 ? p.forced + (uint64_t)rec.slot * p.G : nullptr;
     c.male_nib = p.male_nib;
     c.lut = (const LDS_PTR(u32x4_t))cell_lut;
