@@ -30,7 +30,7 @@ def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=6, help="untimed steps first (the clocks take four or five launches to settle)")
     ap.add_argument("--samples", type=int, default=20000, help="cases + controls (half each)")
     ap.add_argument("--tile-rows", type=int, default=250000, help="SNP rows per step")
     ap.add_argument("--table-rows", type=int, default=5000000, help="SNP rows per GPU (tiles cycle through them)")

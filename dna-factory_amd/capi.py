@@ -11,7 +11,7 @@ import numpy as np
 _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB_PATH = os.environ.get("DNAF_LIB", os.path.join(_CSRC, "libdnaf_hip.so"))
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 OK = 0
 ERR_BAD_ARG, ERR_HIP, ERR_OOM, ERR_UNSUPPORTED, ERR_STATE, ERR_THRESHOLD = -1, -2, -3, -4, -5, -6
@@ -35,7 +35,7 @@ SYMBOLS = [
     "dnaf_format_prefixes", "dnaf_bgzf_compress", "dnaf_read_bgzf", "dnaf_last_bgzf_ms",
     "dnaf_bgzf_tables_from_histogram", "dnaf_gtz_tables_from_histogram", "dnaf_set_mt_state", "dnaf_mt_jump_host", "dnaf_mt_characteristic_polynomial",
     "dnaf_fetch_bgzf", "dnaf_fetch_text", "dnaf_read_text_range", "dnaf_format_snps_json", "dnaf_parse_snps_json",
-    "dnaf_allele_counts", "dnaf_export_bed", "dnaf_read_bed",
+    "dnaf_allele_counts", "dnaf_export_bed", "dnaf_read_bed", "dnaf_packed_pitch_words",
 ]
 
 
@@ -96,6 +96,7 @@ def _load():
         "dnaf_read_text": (ci, [vp, vp, u64, vp]),
         "dnaf_read_packed": (ci, [vp, vp, u64, vp]),
         "dnaf_device_buffers": (ci, [vp, vp, vp, vp, vp]),
+        "dnaf_packed_pitch_words": (ci, [vp, vp]),
         "dnaf_format_prefixes": (ci, [u64, vp, u32, vp, vp, vp, u32, vp, u32, vp, u64, vp]),
         "dnaf_bgzf_compress": (ci, [vp, u32, vp]),
         "dnaf_read_bgzf": (ci, [vp, vp, u64, vp]),
@@ -385,6 +386,11 @@ class Context:
     def last_bgzf_ms(self):
         v = ctypes.c_float(0)
         self._check(lib.dnaf_last_bgzf_ms(self._h, ctypes.byref(v)))
+        return v.value
+
+    def packed_pitch_words(self):
+        v = ctypes.c_uint64(0)
+        self._check(lib.dnaf_packed_pitch_words(self._h, ctypes.byref(v)))
         return v.value
 
     def device_buffers(self):

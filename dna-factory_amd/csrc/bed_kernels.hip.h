@@ -24,13 +24,13 @@ __device__ __forceinline__ uint32_t bed_spread16(uint32_t v)
 }
 
 __global__ __launch_bounds__(256) void bed_kernel(const uint32_t* packed, const RowRec* recs, const uint8_t* male_nib, uint32_t S, uint32_t W,
-                                                  uint32_t G, uint64_t n_rows, uint8_t* bed)
+                                                  uint32_t Wp, uint32_t G, uint64_t n_rows, uint8_t* bed)
 {
     const uint64_t idx = (uint64_t)blockIdx.x * 256u + threadIdx.x;
     if (idx >= n_rows * W) return;
     const uint64_t row = idx / W;
     const uint32_t w = (uint32_t)(idx - row * W);
-    const uint32_t code = packed[idx];
+    const uint32_t code = packed[row * Wp + w]; // rows are Wp words apart
     const uint32_t cls = recs[row].cls;
     uint32_t males = 0;
 #pragma unroll

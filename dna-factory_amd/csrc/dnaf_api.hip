@@ -6,6 +6,7 @@
 // launches the kernel on the context's stream.
 #include "../../include/dnaf.h"
 #include "rowgen_kernels.hip.h"
+#include "rowrun_kernels.hip.h"
 #include "bgzf_kernels.hip.h"
 #include "gtz_kernels.hip.h"
 #include "bed_kernels.hip.h"
@@ -36,7 +37,7 @@ struct dnaf_ctx {
 
     // samples
     bool have_samples = false;
-    uint32_t S = 0, G = 0, W = 0, n_male = 0;
+    uint32_t S = 0, G = 0, W = 0, Wp = 0, n_male = 0; // Wp = packed row pitch on the device, in words (>= W)
     uint64_t x_row_bytes = 0; // cells of an X row
     uint8_t* d_male_nib = nullptr;
     uint32_t* d_ctrl2 = nullptr; // [W] 2-bit-domain mask of the control samples
@@ -120,6 +121,9 @@ struct dnaf_ctx {
 
     // tuning
     uint32_t seg_iters = 32;
+    bool force_segments = false;     // DNAF_FORCE_SEGMENTS=1: always the segment form of the kernel (A/B runs, tests)
+    uint64_t min_run_waves = 8192;   // fewer runs than this and long rows: the segment form fills the GPU better
+    uint32_t force_rpw = 0;          // DNAF_ROWS_PER_WAVE: rows per wave of the line-owning form (tests)
 };
 
 static const size_t MAX_TIMED = 4096;
@@ -185,6 +189,9 @@ int dnaf_create(int device, dnaf_ctx** out)
         delete c;
         return fail(nullptr, DNAF_ERR_HIP, "dnaf_create: %s", hipGetErrorString(e));
     }
+    if (const char* s = getenv("DNAF_FORCE_SEGMENTS")) c->force_segments = atoi(s) != 0;
+    if (const char* s = getenv("DNAF_MIN_RUN_WAVES")) c->min_run_waves = strtoull(s, nullptr, 10);
+    if (const char* s = getenv("DNAF_ROWS_PER_WAVE")) c->force_rpw = (uint32_t)std::min<unsigned long long>(strtoull(s, nullptr, 10), 1u << 20);
     if (const char* s = getenv("DNAF_SEG_ITERS")) {
         int v = atoi(s);
         if (v >= 1 && v <= 4096) c->seg_iters = (uint32_t)v;
@@ -255,6 +262,9 @@ int dnaf_set_samples(dnaf_ctx* c, const uint8_t* flags, uint64_t n_samples)
     c->S = (uint32_t)n_samples;
     c->G = (c->S + 3u) / 4u;
     c->W = (c->S + 15u) / 16u;
+    // device pitch of the packed matrix: whole 128-byte lines per row once a row is long enough for that to cost little
+    // (every line of the matrix then has one writer, rowrun_kernels.hip.h); dense below
+    c->Wp = c->W >= 128u ? (c->W + 31u) / 32u * 32u : c->W;
     c->h_flags.assign(flags, flags + n_samples);
     std::vector<uint8_t> nib(c->G ? c->G : 1, 0);
     std::vector<uint32_t> xoff((size_t)c->G + 1, 0);
@@ -492,89 +502,13 @@ static int grow_outputs(dnaf_ctx* c, uint64_t tbytes, uint64_t pbytes)
     return DNAF_OK;
 }
 
-// The row kernel writes two streams (text, packed matrix) and its speed depends on where the two buffers landed
-// physically: from one allocation to the next the same launch takes 4.25 or 4.55 ms per 250k-row tile at 20k samples
-// (tools/bgzf_experiments/kernel_jitter*.py; either stream alone is stable).  With a table loaded, reserving the
-// buffers therefore tries up to eight placements of the packed matrix -- timing the real kernel on the rows that
-// fit -- and keeps the fastest.  DNAF_NO_PLACEMENT_PROBE=1 switches this off.
-static int probe_placement(dnaf_ctx* c)
-{
-    if (!c->have_snps || c->rng_mode != DNAF_RNG_PHILOX || c->S == 0 || getenv("DNAF_NO_PLACEMENT_PROBE")) return DNAF_OK;
-    if (c->text_cap < (1ull << 30) || c->packed_cap == 0) return DNAF_OK; // small buffers: nothing to gain
-    // rows [0, n) fit both buffers
-    const uint64_t rows = c->h_text_off.size() - 1;
-    uint64_t n = std::min<uint64_t>(rows, c->packed_cap / (4ull * c->W));
-    while (n && c->h_text_off[(size_t)n] > c->text_cap) n = n > 1024 ? n - n / 16 : n - 1;
-    if (n < 1000) return DNAF_OK;
-    auto time_launch = [&](float* best) -> int {
-        *best = 1e30f;
-        for (int i = 0; i < 3; ++i) {
-            if (int rc = dnaf_timing_begin(c)) return rc;
-            if (int rc = dnaf_generate(c, 0, n, DNAF_OUT_TEXT | DNAF_OUT_PACKED)) return rc;
-            float ms = 0.f;
-            if (int rc = dnaf_last_generate_ms(c, &ms)) return rc;
-            if (i && ms < *best) *best = ms; // the first launch warms up
-        }
-        return DNAF_OK;
-    };
-    float best = 0.f;
-    if (int rc = time_launch(&best)) return rc; // fresh buffers and idle clocks: the first rounds only warm up
-    if (int rc = time_launch(&best)) return rc;
-    // Only the packed matrix is moved: re-allocating it alone flips the mode, re-allocating the text never does
-    // (kernel_jitter7.py).  The candidates stay allocated until the choice is made, so that every one of them is a
-    // different placement; the search stops as soon as one is clearly in the fast mode.
-    std::vector<uint8_t*> losers;
-    float worst = best;
-    int rc = DNAF_OK;
-    for (int attempt = 1; attempt < 8 && rc == DNAF_OK && best > 0.96f * worst; ++attempt) {
-        uint8_t* p2 = nullptr;
-        if (hipMalloc((void**)&p2, c->packed_cap + 64) != hipSuccess) {
-            (void)hipGetLastError(); // no room for another placement: keep the best so far
-            break;
-        }
-        std::swap(c->d_packed, p2);
-        float ms = 0.f;
-        rc = time_launch(&ms);
-        worst = std::max(worst, ms);
-        if (rc == DNAF_OK && ms < best) best = ms; // the new one is the one to beat
-        else std::swap(c->d_packed, p2);
-        losers.push_back(p2);
-    }
-    // now and then no placement of the matrix helps: then the text moves as well (a 20 GB hipMalloc takes about 0.6 s)
-    for (int attempt = 0; attempt < 2 && rc == DNAF_OK && best > 0.96f * worst; ++attempt) {
-        uint8_t *t2 = nullptr, *p2 = nullptr;
-        if (hipMalloc((void**)&t2, c->text_cap + 64) != hipSuccess || hipMalloc((void**)&p2, c->packed_cap + 64) != hipSuccess) {
-            (void)hipGetLastError();
-            if (t2) (void)hipFree(t2);
-            break;
-        }
-        std::swap(c->d_text, t2);
-        std::swap(c->d_packed, p2);
-        float ms = 0.f;
-        rc = time_launch(&ms); // fresh text: one round to warm up
-        if (rc == DNAF_OK) rc = time_launch(&ms);
-        worst = std::max(worst, ms);
-        if (rc == DNAF_OK && ms < best) best = ms;
-        else { std::swap(c->d_text, t2); std::swap(c->d_packed, p2); }
-        losers.push_back(t2);
-        losers.push_back(p2);
-    }
-    (void)hipStreamSynchronize(c->stream);
-    for (uint8_t* l : losers) (void)hipFree(l);
-    if (rc) return rc;
-    c->have_output = false;
-    c->have_bgzf = false;
-    return dnaf_timing_begin(c);
-}
-
 int dnaf_reserve_output(dnaf_ctx* c, uint64_t text_bytes, uint64_t packed_words)
 {
     if (!c) return DNAF_ERR_BAD_ARG;
     HIP_TRY(c, hipSetDevice(c->device));
-    const uint8_t *t0 = c->d_text, *p0 = c->d_packed;
-    if (int rc = grow_outputs(c, text_bytes, packed_words * 4u)) return rc;
-    if (c->d_text != t0 || c->d_packed != p0) return probe_placement(c); // new buffers: choose their placement
-    return DNAF_OK;
+    // packed_words counts dense rows of W words; the device rows are Wp words apart
+    const uint64_t rows = c->W ? (packed_words + c->W - 1) / c->W : 0;
+    return grow_outputs(c, text_bytes, rows * (uint64_t)c->Wp * 4u);
 }
 
 // ---- numpy-compatible MT19937 mode (mt_kernels.hip.h) ----
@@ -700,14 +634,14 @@ static int generate_mt(dnaf_ctx* c, uint64_t row_begin, uint64_t n_rows, uint32_
     p.forced = c->d_forced;
     p.text = c->d_text;
     p.packed = c->d_packed;
-    p.packed_pitch = (uint64_t)c->W * 4u;
+    p.packed_pitch = (uint64_t)c->Wp * 4u;
     p.text_base = c->h_text_off[(size_t)row_begin];
     p.row_begin = row_begin;
     p.n_rows = n_rows;
     p.rng_row0 = c->rng_row0;
     p.key0 = p.key1 = 0;
     p.S = c->S; p.G = c->G; p.W = c->W;
-    p.nseg = 1; p.seg_groups = 64;
+    p.nseg = 1; p.seg_groups = 64; p.rows_per_wave = 1;
     mp.thr53 = c->d_thr53;
     mp.states = c->d_mt_states;
     mp.start_off = c->mt_pos == 624 ? 0 : c->mt_pos;
@@ -735,7 +669,7 @@ int dnaf_generate(dnaf_ctx* c, uint64_t row_begin, uint64_t n_rows, uint32_t wha
         return fail(c, DNAF_ERR_BAD_ARG, "dnaf_generate: what = %u", what);
     HIP_TRY(c, hipSetDevice(c->device));
     const uint64_t tbytes = c->h_text_off[(size_t)(row_begin + n_rows)] - c->h_text_off[(size_t)row_begin];
-    const uint64_t pbytes = n_rows * (uint64_t)c->W * 4u;
+    const uint64_t pbytes = n_rows * (uint64_t)c->Wp * 4u;
     if (int rc = grow_outputs(c, (what & DNAF_OUT_TEXT) ? tbytes : 0, (what & DNAF_OUT_PACKED) ? pbytes : 0)) return rc;
     c->last_begin = row_begin;
     c->last_rows = n_rows;
@@ -753,7 +687,7 @@ int dnaf_generate(dnaf_ctx* c, uint64_t row_begin, uint64_t n_rows, uint32_t wha
     p.forced = c->d_forced;
     p.text = c->d_text;
     p.packed = c->d_packed;
-    p.packed_pitch = (uint64_t)c->W * 4u;
+    p.packed_pitch = (uint64_t)c->Wp * 4u;
     p.text_base = c->h_text_off[(size_t)row_begin];
     p.row_begin = row_begin;
     p.n_rows = n_rows;
@@ -761,10 +695,22 @@ int dnaf_generate(dnaf_ctx* c, uint64_t row_begin, uint64_t n_rows, uint32_t wha
     p.key0 = (uint32_t)c->seed;
     p.key1 = (uint32_t)(c->seed >> 32);
     p.S = c->S; p.G = c->G; p.W = c->W;
-    // split a row into nseg balanced segments of at most 64*seg_iters groups, each a multiple of 64 groups
+    // Two forms of the kernel.  Rows of at least 256 groups in a range with enough rows to fill the GPU one run per wave:
+    // the line-owning form (rowrun_kernels.hip.h), a wave per run of whole rows, every 128-byte line of the text has one
+    // writer.  Otherwise (short rows, or a few very long ones): a wave per row segment (rowgen_kernels.hip.h).
     p.nseg = c->G ? (c->G + 64u * c->seg_iters - 1) / (64u * c->seg_iters) : 1;
     p.seg_groups = c->G ? ((c->G + p.nseg - 1) / p.nseg + 63u) / 64u * 64u : 64u;
-    const uint64_t items = n_rows * p.nseg;
+    uint64_t row_bytes_min = 2ull * c->S; // a Y / MT row's cells; every row is longer
+    uint32_t rpw = 1;
+    if (c->G >= 256u) {
+        // ~64 KiB of text per wave, but never fewer than ~16k waves while the range has the rows for it
+        rpw = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(64, 65536ull / (4ull * c->S)));
+        while (rpw > 1 && n_rows / rpw < 16384) rpw /= 2;
+        if (c->force_rpw) rpw = c->force_rpw;
+    }
+    const bool use_runs = c->G >= 256u && row_bytes_min >= 256 && !c->force_segments && (p.nseg == 1 || n_rows / rpw >= c->min_run_waves);
+    p.rows_per_wave = rpw;
+    const uint64_t items = use_runs ? (n_rows + rpw - 1) / rpw : n_rows * p.nseg;
     const uint64_t blocks = (items + 3) / 4;
     if (blocks > 0x7FFFFFFFull) return fail(c, DNAF_ERR_UNSUPPORTED, "dnaf_generate: %llu workgroups; generate fewer rows per call", (unsigned long long)blocks);
     // one event pair per launch, on the launch stream (pool bounded: later launches go unrecorded)
@@ -778,7 +724,11 @@ int dnaf_generate(dnaf_ctx* c, uint64_t row_begin, uint64_t n_rows, uint32_t wha
     }
     if (rec) HIP_TRY(c, hipEventRecord(c->evs[2 * c->n_timed], c->stream));
     const dim3 grid((uint32_t)blocks), block(256);
-    if (what == (DNAF_OUT_TEXT | DNAF_OUT_PACKED)) hipLaunchKernelGGL((dnaf::rowgen_kernel<true, true>), grid, block, 0, c->stream, p);
+    if (use_runs) {
+        if (what == (DNAF_OUT_TEXT | DNAF_OUT_PACKED)) hipLaunchKernelGGL((dnaf::rowrun_kernel<true, true>), grid, block, 0, c->stream, p);
+        else if (what == DNAF_OUT_TEXT) hipLaunchKernelGGL((dnaf::rowrun_kernel<true, false>), grid, block, 0, c->stream, p);
+        else hipLaunchKernelGGL((dnaf::rowrun_kernel<false, true>), grid, block, 0, c->stream, p);
+    } else if (what == (DNAF_OUT_TEXT | DNAF_OUT_PACKED)) hipLaunchKernelGGL((dnaf::rowgen_kernel<true, true>), grid, block, 0, c->stream, p);
     else if (what == DNAF_OUT_TEXT) hipLaunchKernelGGL((dnaf::rowgen_kernel<true, false>), grid, block, 0, c->stream, p);
     else hipLaunchKernelGGL((dnaf::rowgen_kernel<false, true>), grid, block, 0, c->stream, p);
     HIP_TRY(c, hipGetLastError());
@@ -868,7 +818,7 @@ int dnaf_allele_counts(dnaf_ctx* c, uint32_t* counts, uint64_t cap_rows)
         c->counts_cap = n;
     }
     hipLaunchKernelGGL(dnaf::allele_count_kernel, dim3((uint32_t)((n + 3) / 4)), dim3(256), 0, c->stream,
-                       (const uint32_t*)c->d_packed, (const uint32_t*)c->d_ctrl2, c->W, n, c->d_counts);
+                       (const uint32_t*)c->d_packed, (const uint32_t*)c->d_ctrl2, c->W, c->Wp, n, c->d_counts);
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipMemcpyAsync(counts, c->d_counts, n * 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -895,7 +845,7 @@ int dnaf_export_bed(dnaf_ctx* c, uint64_t* n_bytes)
     }
     const uint64_t words = n * c->W;
     hipLaunchKernelGGL(dnaf::bed_kernel, dim3((uint32_t)((words + 255) / 256)), dim3(256), 0, c->stream, (const uint32_t*)c->d_packed,
-                       (const RowRec*)(c->d_recs + c->last_begin), (const uint8_t*)c->d_male_nib, c->S, c->W, c->G, n, c->d_bed);
+                       (const RowRec*)(c->d_recs + c->last_begin), (const uint8_t*)c->d_male_nib, c->S, c->W, c->Wp, c->G, n, c->d_bed);
     HIP_TRY(c, hipGetLastError());
     c->have_bed = true;
     return DNAF_OK;
@@ -935,8 +885,17 @@ int dnaf_read_packed(dnaf_ctx* c, uint32_t* dst, uint64_t dst_cap_words, uint64_
     if (n > dst_cap_words) return fail(c, DNAF_ERR_BAD_ARG, "dnaf_read_packed: need %llu words, have %llu", (unsigned long long)n, (unsigned long long)dst_cap_words);
     if (n && !dst) return fail(c, DNAF_ERR_BAD_ARG, "dnaf_read_packed: dst is NULL");
     HIP_TRY(c, hipSetDevice(c->device));
-    if (n) HIP_TRY(c, hipMemcpyAsync(dst, c->d_packed, n * 4, hipMemcpyDeviceToHost, c->stream));
+    // the device rows are Wp words apart; the caller gets the dense [n_rows][W] matrix
+    if (n) HIP_TRY(c, hipMemcpy2DAsync(dst, (size_t)c->W * 4, c->d_packed, (size_t)c->Wp * 4, (size_t)c->W * 4, (size_t)c->last_rows, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return DNAF_OK;
+}
+
+int dnaf_packed_pitch_words(const dnaf_ctx* c, uint64_t* pitch_words)
+{
+    if (!c || !pitch_words) return DNAF_ERR_BAD_ARG;
+    if (!c->have_samples) return fail(const_cast<dnaf_ctx*>(c), DNAF_ERR_STATE, "dnaf_packed_pitch_words: call dnaf_set_samples first");
+    *pitch_words = c->Wp;
     return DNAF_OK;
 }
 
@@ -948,7 +907,7 @@ int dnaf_device_buffers(dnaf_ctx* c, void** d_text, uint64_t* text_bytes, void**
     if (d_text) *d_text = t ? c->d_text : nullptr;
     if (text_bytes) *text_bytes = t ? c->h_text_off[(size_t)(c->last_begin + c->last_rows)] - c->h_text_off[(size_t)c->last_begin] : 0;
     if (d_packed) *d_packed = k ? c->d_packed : nullptr;
-    if (packed_words) *packed_words = k ? c->last_rows * (uint64_t)c->W : 0;
+    if (packed_words) *packed_words = k ? c->last_rows * (uint64_t)c->Wp : 0; // rows are dnaf_packed_pitch_words() apart
     return DNAF_OK;
 }
 
@@ -1033,6 +992,7 @@ int dnaf_bgzf_compress(dnaf_ctx* c, uint32_t flags, uint64_t* n_bytes)
         g.n_blocks = nb;
         g.S = (uint32_t)c->S;
         g.W = c->W;
+        g.Wp = c->Wp;
         g.sample_step = nb > 2048 ? nb / 2048 : 1;
         g.tables = c->d_gtz_tables;
         g.member_row = c->d_member_row;

@@ -54,12 +54,12 @@ static_assert(GTZ_MAX_CHUNKS * GTZ_MAX_FAR >= 2 * GTZ_KEYS, "the match lists len
 struct GtzParams {
     const RowRec* recs;      // [table rows]
     const uint8_t* prefix;   // prefix blob
-    const uint32_t* packed;  // [n_rows][W] genotype matrix of this call
+    const uint32_t* packed;  // [n_rows] rows of W words, Wp words apart: genotype matrix of this call
     uint64_t text_base;      // recs[row_begin].text_off
     uint64_t row_begin, n_rows;
     uint64_t n_bytes;        // text bytes of the call
     uint32_t n_blocks;
-    uint32_t S, W;
+    uint32_t S, W, Wp;
     uint32_t sample_step;    // gtz_hist: every sample_step-th member
     const GtzTables* tables;
     uint32_t* member_row;    // [n_blocks] table row that holds the member's first byte (gtz_locate)
@@ -270,7 +270,7 @@ __device__ __forceinline__ uint32_t gtz_text_byte(const GtzParams& p, const GtzS
     const uint32_t k = (uint32_t)c >> 2, which = (uint32_t)c & 3u;
     if (which == 1u) return '/';
     if (which == 3u) return k == p.S - 1u ? '\n' : '\t';
-    const uint32_t w = p.packed[(uint64_t)(m_row + j) * p.W + (k >> 4)];
+    const uint32_t w = p.packed[(uint64_t)(m_row + j) * p.Wp + (k >> 4)];
     const uint32_t code = (w >> (2u * (k & 15u))) & 3u;
     return '0' + (which == 0u ? (code & 1u) : (code >> 1));
 }
@@ -361,7 +361,7 @@ __global__ __launch_bounds__(GTZ_THREADS) void gtz_encode(const GtzParams p)
     // ---- g space, key tables, code tables ----
     for (uint32_t i = 0; i < nr; ++i) {
         const uint32_t nw = s->gw[i + 1] - s->gw[i];
-        const uint32_t* src = p.packed + (uint64_t)(m_row + i) * p.W;
+        const uint32_t* src = p.packed + (uint64_t)(m_row + i) * p.Wp;
         for (uint32_t w = tid; w < nw; w += GTZ_THREADS) {
             const uint32_t kw = s->kw0[i] + w;
             s->cells[s->gw[i] + w] = kw < p.W ? src[kw] : 0u;

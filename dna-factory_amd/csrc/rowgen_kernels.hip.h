@@ -51,6 +51,7 @@ struct GenParams {
     uint32_t key0, key1;       // Philox key = seed
     uint32_t S, G, W;          // samples, groups of 4, packed words per row
     uint32_t nseg, seg_groups; // segments per row, groups per segment (multiple of 64)
+    uint32_t rows_per_wave;    // rowrun_kernel: whole rows per wave
 };
 
 #define PHILOX_M0 0xD2511F53u
@@ -321,19 +322,35 @@ __device__ __forceinline__ void haploid_fast(const SegCtx& c, uint32_t g)
                               (m & 8u ? nz(a3) : 0u) << 6);
 }
 
+// The low N bytes of val at c.cells + off, restricted to the cell-stream offsets [lo, hi) (the bytes this wave owns)
+template <int N>
+__device__ __forceinline__ void store_clipped(uint8_t* cells, uint32_t off, uint32_t val, uint32_t lo, uint32_t hi)
+{
+    if (off >= lo && off + N <= hi) {
+        if (N == 4) store_unaligned<4>(cells + off, &val);
+        else { const uint16_t h = (uint16_t)val; store_unaligned<2>(cells + off, &h); }
+        return;
+    }
+#pragma unroll
+    for (int b = 0; b < N; ++b)
+        if (off + b >= lo && off + b < hi) cells[off + b] = (uint8_t)(val >> (8 * b));
+}
+
 // Any group of any row class, cell by cell: used for the row's last group (newline, fewer than 4
-// samples), the pad bytes of the packed row, and multi-allelic X rows.
-template <bool TEXT, bool PACKED, bool MULTI>
-__device__ __forceinline__ void general_group(const SegCtx& c, uint32_t cls, uint32_t g)
+// samples), the pad bytes of the packed row, multi-allelic X rows, and -- with CLIP -- for the few groups at
+// the ends of a wave's line range, where only the text bytes at cell-stream offsets [lo, hi) are stored.
+// STAGE: the packed byte goes to the wave's LDS ring (c.stage, index g mod PK_RING) instead of c.prow.
+template <bool TEXT, bool PACKED, bool MULTI, bool CLIP = false, bool STAGE = false>
+__device__ __forceinline__ void general_group(const SegCtx& c, uint32_t cls, uint32_t g, uint32_t lo = 0u, uint32_t hi = 0xFFFFFFFFu)
 {
     if (g >= c.G) { // lanes past the last group only zero the pad bytes of the packed row
-        if (PACKED) c.prow[g] = 0;
+        if (PACKED) { if (STAGE) c.stage[g & (PK_STAGE - 1u)] = 0; else c.prow[g] = 0; }
         return;
     }
     uint32_t a[4], b[4];
     group_alleles<MULTI>(c, g, a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]);
     const uint32_t male = c.male_nib[g];
-    uint8_t* dst = c.cells + (cls == 0u ? 16ull * g : (cls == 1u ? (uint64_t)c.xoff[g] : 8ull * g));
+    uint32_t off = cls == 0u ? 16u * g : (cls == 1u ? c.xoff[g] : 8u * g);
     uint32_t pk = 0;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -344,17 +361,29 @@ __device__ __forceinline__ void general_group(const SegCtx& c, uint32_t cls, uin
             const bool missing = cls == 2u && !is_male;                           // pop_factory.py:481-484
             const bool haploid = cls >= 2u || (cls == 1u && is_male);             // common/snp.py:102-109
             if (missing) {
-                if (TEXT) { const uint16_t h = (uint16_t)HAPLOID_CELL(0x2Eu, sep); store_unaligned<2>(dst, &h); dst += 2; }
+                if (TEXT) {
+                    const uint16_t h = (uint16_t)HAPLOID_CELL(0x2Eu, sep);
+                    if (CLIP) store_clipped<2>(c.cells, off, h, lo, hi); else store_unaligned<2>(c.cells + off, &h);
+                    off += 2;
+                }
             } else if (haploid) {
                 pk |= nz(a[k]) << (2 * k);
-                if (TEXT) { const uint16_t h = (uint16_t)HAPLOID_CELL(0x30u + a[k], sep); store_unaligned<2>(dst, &h); dst += 2; }
+                if (TEXT) {
+                    const uint16_t h = (uint16_t)HAPLOID_CELL(0x30u + a[k], sep);
+                    if (CLIP) store_clipped<2>(c.cells, off, h, lo, hi); else store_unaligned<2>(c.cells + off, &h);
+                    off += 2;
+                }
             } else {
                 pk |= (nz(a[k]) | nz(b[k]) << 1) << (2 * k);
-                if (TEXT) { const uint32_t w = DIPLOID_CELL(a[k], b[k], sep); store_unaligned<4>(dst, &w); dst += 4; }
+                if (TEXT) {
+                    const uint32_t w = DIPLOID_CELL(a[k], b[k], sep);
+                    if (CLIP) store_clipped<4>(c.cells, off, w, lo, hi); else store_unaligned<4>(c.cells + off, &w);
+                    off += 4;
+                }
             }
         }
     }
-    if (PACKED) c.prow[g] = (uint8_t)pk;
+    if (PACKED) { if (STAGE) c.stage[g & (PK_STAGE - 1u)] = (uint8_t)pk; else c.prow[g] = (uint8_t)pk; }
 }
 
 template <bool TEXT, bool PACKED, bool MULTI>
@@ -523,13 +552,13 @@ __global__ __launch_bounds__(256) void rowgen_kernel(const GenParams p)
 // Case / control allele counts from the packed matrix (the check behind BASELINE config 5: per-SNP
 // alternative-allele frequency of cases vs controls).  One wave per row: popcounts of the row's words
 // split by the control mask (both bits of a control sample's code set in ctrl2), wave-reduced.
-__global__ __launch_bounds__(256) void allele_count_kernel(const uint32_t* packed, const uint32_t* ctrl2, uint32_t W,
+__global__ __launch_bounds__(256) void allele_count_kernel(const uint32_t* packed, const uint32_t* ctrl2, uint32_t W, uint32_t Wp,
                                                            uint64_t n_rows, uint32_t* counts)
 {
     const uint32_t lane = threadIdx.x & 63u;
     const uint64_t row = (uint64_t)blockIdx.x * 4u + (threadIdx.x >> 6);
     if (row >= n_rows) return;
-    const uint32_t* p = packed + row * W;
+    const uint32_t* p = packed + row * Wp; // rows are Wp words apart
     uint32_t nc = 0, nk = 0;
     for (uint32_t w = lane; w < W; w += 64u) {
         const uint32_t v = p[w], m = ctrl2[w];

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define DNAF_ABI_VERSION 1
+#define DNAF_ABI_VERSION 2 /* 2: the device copy of the packed matrix has a row pitch (dnaf_packed_pitch_words) */
 
 #define DNAF_OK 0
 #define DNAF_ERR_BAD_ARG (-1)
@@ -122,12 +122,9 @@ int dnaf_row_offsets(const dnaf_ctx* ctx, uint64_t row_begin, uint64_t n_rows, u
  * context's stream; grows the output buffers if needed (a growth
  * synchronises the device). */
 int dnaf_generate(dnaf_ctx* ctx, uint64_t row_begin, uint64_t n_rows, uint32_t what);
-/* Size the output buffers ahead of time so that no later dnaf_generate has to grow them.  With a
- * table loaded, Philox mode and more than 1 GiB of text, the call also chooses where the two buffers
- * live: it times the row kernel on up to eight allocations of the packed matrix (and, rarely, two
- * of the text) and keeps the fastest -- the kernel runs 7 % slower on some physical placements of
- * the matrix, DESIGN.md section 5.  Usually 0.1 s, a few seconds when the text has to move too.
- * DNAF_NO_PLACEMENT_PROBE=1 in the environment turns the search off. */
+/* Size the output buffers ahead of time so that no later dnaf_generate has to grow them: text_bytes of
+ * VCF text and packed_words = rows * ceil(S/16) words of the matrix (dense count; the library adds the
+ * padding of its device pitch itself). */
 int dnaf_reserve_output(dnaf_ctx* ctx, uint64_t text_bytes, uint64_t packed_words);
 int dnaf_sync(dnaf_ctx* ctx);
 
@@ -163,8 +160,14 @@ int dnaf_export_bed(dnaf_ctx* ctx, uint64_t* n_bytes);
 int dnaf_read_bed(dnaf_ctx* ctx, void* dst, uint64_t dst_cap, uint64_t* n_bytes);
 
 /* Device pointers of the last generated range, for consumers that stay on
- * the GPU (valid until the next dnaf_generate / dnaf_destroy). */
+ * the GPU (valid until the next dnaf_generate / dnaf_destroy).  In device memory row j of the
+ * matrix starts dnaf_packed_pitch_words() words after row j-1 and holds ceil(S/16) words;
+ * packed_words = rows * pitch.  (dnaf_read_packed returns the dense matrix.) */
 int dnaf_device_buffers(dnaf_ctx* ctx, void** d_text, uint64_t* text_bytes, void** d_packed, uint64_t* packed_words);
+/* Row pitch of the device copy of the packed matrix, in 32-bit words: ceil(S/16) rounded up to whole
+ * 128-byte lines once a row is at least 512 bytes long (so that every line of the matrix is stored by
+ * exactly one wave), ceil(S/16) below that.  Known after dnaf_set_samples. */
+int dnaf_packed_pitch_words(const dnaf_ctx* ctx, uint64_t* pitch_words);
 
 /* On-GPU BGZF encoder -- the sink right after the path (the reference pushes every line through
  * Bio.bgzf.BgzfWriter, pop_factory.py:403, :449).  Compresses the text of the last dnaf_generate

@@ -249,9 +249,9 @@ def test_bed_export_matches_the_text(RowGenerator, n_rows, S):
             assert codes[i] == want, (j, i, cell)
 
 
-def test_reserve_output_probes_placements_and_results_stay_exact(RowGenerator, oracle):
-    """dnaf_reserve_output with a table loaded and more than 1 GiB of text times the kernel on up to four placements
-    of the two output buffers and keeps the fastest; whatever it keeps, the rows are the oracle's."""
+def test_reserved_buffers_and_a_large_tile_stay_exact(RowGenerator, oracle):
+    """dnaf_reserve_output sizes both buffers up front (dense word count in, padded device pitch inside); a 1.1 GB tile
+    generated into them is the oracle's at both ends, and the reservation is not re-allocated by the launch."""
     from dna_factory_amd.tables import SampleTable, SnpTable
 
     S, n = 20000, 14000
@@ -267,14 +267,54 @@ def test_reserve_output_probes_placements_and_results_stay_exact(RowGenerator, o
         g.set_samples(st)
         g.set_snps(tb)
         assert g.ctx.text_bytes(0, n) > 1 << 30
+        assert g.ctx.packed_pitch_words() == 1280 and g.words_per_row == 1250  # whole 128-byte lines per row
         g.ctx.reserve_output(g.ctx.text_bytes(0, n), n * g.words_per_row)
+        g.ctx.generate(0, 1, 3)
+        before = g.ctx.device_buffers()
         g.ctx.generate(0, n, 3)
+        after = g.ctx.device_buffers()
+        assert (before[0], before[2]) == (after[0], after[2]) and after[3] == n * 1280
         off = g.ctx.row_offsets(0, n)
         for b in (0, n - 40):
             text = g.ctx.read_text_range(int(off[b]), int(off[b + 40] - off[b]))
             want, _, want_packed = oracle.generate(oracle.table_records(tb, b, b + 40), sex, ctrl, doff, dids, seed=44, rng_row0=b)
             assert text.tobytes() == want
         assert np.array_equal(g.ctx.read_packed(n, g.words_per_row)[n - 40:], want_packed)
+
+
+@pytest.mark.parametrize("rpw", [1, 2, 3, 8, 64])
+def test_line_owning_kernel_fuzz(RowGenerator, oracle, monkeypatch, rpw):
+    """The line-owning form of the kernel (rowrun_kernels.hip.h: a wave stores whole 128-byte lines, i.e. its rows
+    minus the first bytes of its first row plus the first bytes of the next wave's first row), forced on for small
+    tables and for 1 .. 64 rows per wave: every chromosome class, forced cells, 1-4 alleles, sample counts around the
+    staging ring's boundaries (1024 / 2048 groups) and the padded / dense pitch switch (W = 128 words at S = 2033)."""
+    monkeypatch.setenv("DNAF_MIN_RUN_WAVES", "0")
+    monkeypatch.setenv("DNAF_ROWS_PER_WAVE", str(rpw))
+    rs = np.random.RandomState(777 + rpw)
+    pools = [range(1021, 1100), range(2029, 2052), range(4090, 4104), range(8186, 8200), range(12280, 12300), range(20000, 20004)]
+    for case in range(18):
+        S = int(rs.choice(list(pools[case % len(pools)])))
+        n_rows = int(rs.randint(1, 12 if S > 4000 else 70))
+        snps, samples = random_case(rs, n_rows, S, p_sex_chrom=0.4)
+        check_case(RowGenerator, oracle, snps, samples, seed=int(rs.randint(0, 2**31)), rng_row0=int(rs.randint(0, 1000)))
+
+
+def test_both_kernel_forms_write_the_same_bytes(RowGenerator, oracle, monkeypatch):
+    """DNAF_FORCE_SEGMENTS=1 (a wave per row segment) and the default line-owning form on one mid-size table."""
+    rs = np.random.RandomState(5150)
+    snps, samples = random_case(rs, 300, 3000, p_sex_chrom=0.5)
+    outs = []
+    for force in ("1", "0"):
+        monkeypatch.setenv("DNAF_FORCE_SEGMENTS", force)
+        monkeypatch.setenv("DNAF_MIN_RUN_WAVES", "0")
+        with RowGenerator(device=0, seed=12) as g:
+            g.set_samples(samples)
+            g.set_snps(snps)
+            t, off, p = g.generate()
+            outs.append((t.tobytes(), off.tobytes(), p.tobytes()))
+    assert outs[0] == outs[1]
+    want_text, _, want_packed = oracle_run(oracle, snps, samples, 12)
+    assert outs[0][0] == want_text and outs[0][2] == want_packed.tobytes()
 
 
 def test_hip_matches_oracle_fuzz(RowGenerator, oracle):
