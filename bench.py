@@ -79,6 +79,33 @@ def synthetic_samples(S, n_rows_table, snp_ids, rs):
     return SampleTable(flags, slot_ids[order], off, np.asarray(idx, dtype=np.uint32))
 
 
+def kernel_source_hash():
+    """SHA-256 of the row kernels' sources: what a PMC traffic figure has to have been measured on."""
+    import hashlib
+
+    h = hashlib.sha256()
+    for f in ("rowgen_kernels.hip.h", "rowrun_kernels.hip.h"):
+        with open(os.path.join(ROOT, "dna-factory_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def load_traffic(a, S):
+    """HBM bytes per launch from the committed rocprofv3 --pmc passes (tools/pmc_traffic.py) -- only when they were taken
+    on this very kernel source and workload; otherwise null, with the reason."""
+    if not os.path.exists(a.traffic_json):
+        return None, "no PMC file (%s)" % os.path.relpath(a.traffic_json, ROOT)
+    try:
+        tj = json.load(open(a.traffic_json))
+    except (OSError, ValueError) as e:
+        return None, "unreadable PMC file: %s" % e
+    if not (tj.get("samples") == S and tj.get("tile_rows") == a.tile_rows and tj.get("what") == a.what):
+        return None, "PMC file is for another workload"
+    if tj.get("kernel_source_sha16") != kernel_source_hash():
+        return None, "PMC file was measured on other kernel sources (%s, now %s)" % (tj.get("kernel_source_sha16"), kernel_source_hash())
+    return tj.get("hbm_bytes_per_launch"), "rocprofv3 --pmc WRITE_SIZE / FETCH_SIZE passes of this command, %s" % os.path.relpath(a.traffic_json, ROOT)
+
+
 def cpu_baseline(tb, st, seed, target_seconds):
     """Time the CPU oracle (oracle/rowgen_oracle.c, the checker -- never the product) on cores-1 host threads over
     a bounded prefix of the same workload."""
@@ -144,91 +171,130 @@ def cpu_baseline(tb, st, seed, target_seconds):
                       "pop_factory.py:471-513, Philox draws) on %d threads, %.1f s" % (n, S, cores, dt)}
 
 
+class _Rank:
+    """One GPU's share of the benchmark: its own SNP range of the global table, its own context."""
+
+    def __init__(self, a, rank, device):
+        from dna_factory_amd import capi
+        from dna_factory_amd.genome import synthetic_snp_table
+        from dna_factory_amd.rowgen import RowGenerator
+
+        self.a, self.rank = a, rank
+        S = a.samples
+        rows = max(a.table_rows, a.tile_rows)
+        rs = np.random.RandomState(a.table_seed + 1000 * rank)
+        tb = synthetic_snp_table(rows, a.min_maf, rs)
+        self.st = synthetic_samples(S, rows, tb.snp_id, np.random.RandomState(a.table_seed))  # same samples on every rank
+        self.gen = gen = RowGenerator(device=device, seed=a.seed, rng=a.rng)
+        gen.set_samples(self.st)
+        q = gen.row_quantum
+        self.tile_rows = max(q, a.tile_rows // q * q)
+        rows = max(self.tile_rows, rows // self.tile_rows * self.tile_rows)
+        if rows < len(tb):
+            tb = tb.slice(0, rows)
+        self.tb, self.rows = tb, rows
+        gen.set_snps(tb, rng_row0=rank * rows)  # this rank's SNP range of the global table
+        self.what = {"text+packed": capi.OUT_TEXT | capi.OUT_PACKED, "text": capi.OUT_TEXT, "packed": capi.OUT_PACKED}[a.what]
+        self.n_tiles = max(1, rows // self.tile_rows)
+        # size the output buffers for the largest tile up front: no allocation inside the timed region
+        gen.ctx.reserve_output(max(gen.ctx.text_bytes(t * self.tile_rows, self.tile_rows) for t in range(self.n_tiles)),
+                               self.tile_rows * gen.words_per_row)
+
+    def step(self, i):
+        self.gen.ctx.generate((i % self.n_tiles) * self.tile_rows, self.tile_rows, self.what)
+
+    def run(self, barrier):
+        """W untimed steps, then exactly K steps between two barriers; -> (wall seconds, kernel ms, launches recorded)."""
+        a = self.a
+        for i in range(a.warmup):
+            self.step(i)
+        self.gen.ctx.sync()
+        barrier()
+        self.gen.ctx.timing_begin()
+        t0 = time.perf_counter()
+        for i in range(a.steps):
+            self.step(a.warmup + i)
+        self.gen.ctx.sync()
+        t1 = time.perf_counter()
+        barrier()
+        kern_ms, n_rec, _ = self.gen.ctx.timing_end()
+        return t1 - t0, kern_ms, n_rec
+
+
 def main():
     a = parse_args()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    n = max(a.gpus, 1)
+    env_world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != max(a.gpus, 1) and world > 1:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (a.gpus, world))
-    dist = None
-    # rehearsal knobs (tests on a one-GPU box only): DNAF_BENCH_BACKEND=gloo keeps the collectives on the CPU and
-    # DNAF_BENCH_SHARE_GPU=1 lets several ranks share GPU 0; the driver's runs use neither.
-    backend = os.environ.get("DNAF_BENCH_BACKEND", "nccl")
-    if os.environ.get("DNAF_BENCH_SHARE_GPU"):
-        local_rank = 0
-    if world > 1:
-        import torch
-        import torch.distributed as dist
-
-        torch.cuda.set_device(local_rank)
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(backend)
+    if env_world > 1 and env_world != n:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (a.gpus, env_world))
+    share_gpu = bool(os.environ.get("DNAF_BENCH_SHARE_GPU"))  # rehearsal on a one-GPU box: every rank on GPU 0
 
     import __graft_entry__ as ge
 
     if not os.path.exists(os.path.join(ROOT, "dna-factory_amd", "csrc", "libdnaf_hip.so")):
         ge.build()
     from dna_factory_amd import capi
-    from dna_factory_amd.genome import synthetic_snp_table
-    from dna_factory_amd.rowgen import RowGenerator
 
-    S = a.samples
-    rows = max(a.table_rows, a.tile_rows)
-    rs = np.random.RandomState(a.table_seed + 1000 * rank)
-    tb = synthetic_snp_table(rows, a.min_maf, rs)
-    st = synthetic_samples(S, rows, tb.snp_id, np.random.RandomState(a.table_seed))  # same samples on every rank
-    gen = RowGenerator(device=local_rank, seed=a.seed, rng=a.rng)
-    gen.set_samples(st)
-    q = gen.row_quantum
-    a.tile_rows = max(q, a.tile_rows // q * q)
-    rows = max(a.tile_rows, rows // a.tile_rows * a.tile_rows)
-    if rows < len(tb):
-        tb = tb.slice(0, rows)
-    gen.set_snps(tb, rng_row0=rank * rows)  # this rank's SNP range of the global table
-    what = {"text+packed": capi.OUT_TEXT | capi.OUT_PACKED, "text": capi.OUT_TEXT, "packed": capi.OUT_PACKED}[a.what]
-    n_tiles = max(1, rows // a.tile_rows)
+    # never report n_gpus GPUs without having used that many
+    have = capi.device_count()
+    if not share_gpu and have < n:
+        raise SystemExit("--gpus %d but this node shows %d GPU(s)" % (n, have))
 
-    # size the output buffers for the largest tile up front: no allocation inside the timed region
-    gen.ctx.reserve_output(max(gen.ctx.text_bytes(t * a.tile_rows, a.tile_rows) for t in range(n_tiles)),
-                           a.tile_rows * gen.words_per_row)
-
-    def step(i):
-        gen.ctx.generate((i % n_tiles) * a.tile_rows, a.tile_rows, what)
-
-    def barrier():
-        gen.ctx.sync()
-        if dist is not None:
-            dist.barrier()
-            import torch
-
-            torch.cuda.synchronize()
-
-    for i in range(a.warmup):
-        step(i)
-    barrier()
-    gen.ctx.timing_begin()
-    t0 = time.perf_counter()
-    for i in range(a.steps):
-        step(a.warmup + i)
-    gen.ctx.sync()
-    if dist is not None:
+    per_rank_s = None
+    if env_world > 1:
+        # one process per GPU under a launcher (torchrun): the shards never exchange data, so the only collectives are
+        # the benchmark's own barrier and max -- on the CPU (gloo), no RCCL
         import torch
+        import torch.distributed as dist
 
-        torch.cuda.synchronize()
-    t1 = time.perf_counter()
-    barrier()
-    kern_ms, n_rec, n_launch = gen.ctx.timing_end()
-    from dna_factory_amd.sharding import max_over_ranks
+        dist.init_process_group("gloo")
+        r = _Rank(a, rank, 0 if share_gpu else local_rank)
+        wall, kern_ms, n_rec = r.run(dist.barrier)
+        t = torch.tensor([wall], dtype=torch.float64)
+        gathered = [torch.zeros(1, dtype=torch.float64) for _ in range(env_world)]
+        dist.all_gather(gathered, t)
+        per_rank_s = [float(x.item()) for x in gathered]
+        world, launcher = env_world, "one process per GPU (torchrun), gloo barrier"
+    elif n > 1:
+        # stand-alone: one context per GPU, one host thread each (the product's own model, cli.py), a thread barrier
+        import threading
 
-    elapsed = max_over_ranks(t1 - t0, dist, "cuda" if (dist is not None and backend == "nccl") else None)
+        bar = threading.Barrier(n)
+        ranks, results, errors = [None] * n, [None] * n, []
 
+        def work(g):
+            try:
+                ranks[g] = _Rank(a, g, 0 if share_gpu else g)
+                results[g] = ranks[g].run(bar.wait)
+            except BaseException as e:  # noqa: BLE001 -- a dead rank must not leave the others at the barrier
+                errors.append((g, e))
+                bar.abort()
+
+        threads = [threading.Thread(target=work, args=(g,)) for g in range(n)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        if errors:
+            raise SystemExit("rank %d failed: %r" % errors[0])
+        per_rank_s = [res[0] for res in results]
+        r, (wall, kern_ms, n_rec) = ranks[0], results[0]
+        world, launcher = n, "one process, one host thread and one context per GPU"
+    else:
+        r = _Rank(a, 0, 0)
+        wall, kern_ms, n_rec = r.run(lambda: None)
+        per_rank_s = [wall]
+        world, launcher = 1, "single GPU"
+    elapsed = max(per_rank_s)
+
+    gen, tb, st, S, what = r.gen, r.tb, r.st, a.samples, r.what
+    a.tile_rows, rows, n_tiles = r.tile_rows, r.rows, r.n_tiles
     if rank == 0:
         # algorithmic bytes of one launch (SURVEY 8(d)): packed row + text row + 32-byte SNP record, per row
         tiles_used = [(a.warmup + i) % n_tiles for i in range(a.steps)]
-        text_b = np.mean([gen.ctx.text_bytes(t * a.tile_rows, a.tile_rows) for t in set(tiles_used)])
+        text_b = np.mean([gen.ctx.text_bytes(t * a.tile_rows, a.tile_rows) for t in tiles_used])
         bytes_per_launch = 32.0 * a.tile_rows
         if what & capi.OUT_TEXT:
             bytes_per_launch += text_b
@@ -236,14 +302,7 @@ def main():
             bytes_per_launch += a.tile_rows * 4.0 * gen.words_per_row
         mean_kernel_s = (kern_ms / max(n_rec, 1)) * 1e-3
         achieved = bytes_per_launch / mean_kernel_s / 1e9
-        traffic = None
-        if os.path.exists(a.traffic_json):
-            try:
-                tj = json.load(open(a.traffic_json))
-                if tj.get("samples") == S and tj.get("tile_rows") == a.tile_rows and tj.get("what") == a.what:
-                    traffic = tj.get("hbm_bytes_per_launch")
-            except (OSError, ValueError):
-                pass
+        traffic, traffic_source = load_traffic(a, S)
         total_rows = a.steps * a.tile_rows * world
         out = {
             "metric": "SNP-rows/sec at fixed #samples",
@@ -263,11 +322,13 @@ def main():
                                    "streamed in row tiles; outputs resident in HBM",
                        "samples": S, "tile_rows": a.tile_rows, "table_rows_per_gpu": rows, "min_maf": a.min_maf,
                        "outputs": a.what, "rng": "philox4x32-10" if a.rng == "philox" else "mt19937 (numpy legacy)", "seed": a.seed, "table_seed": a.table_seed,
-                       "sharding": "SNP-range per GPU, no collective"},
+                       "sharding": "SNP-range per GPU, no collective", "launcher": launcher,
+                       "per_gpu_wall_s": per_rank_s},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "frac_of_measured_copy_6290_GBs": achieved / 6290.0, "traffic": traffic,
+                         "traffic_source": traffic_source,
                          "bytes_per_launch": bytes_per_launch, "kernel_ms_mean": mean_kernel_s * 1e3,
-                         "launches_timed": n_rec, "kernel": "rowgen_kernel" if a.rng == "philox" else "mt_rowgen_kernel (+ mt_jump_kernel)",
+                         "launches_timed": n_rec, "kernel": "rowrun_kernel" if a.rng == "philox" else "mt_rowgen_kernel (+ mt_jump_kernel)",
                          "draws_per_s": 2.0 * S * a.tile_rows / mean_kernel_s},
         }
         if a.bgzf_tiles > 0 and (what & capi.OUT_TEXT):
@@ -288,8 +349,9 @@ def main():
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
-    gen.close()
-    if dist is not None:
+    if env_world > 1:
+        import torch.distributed as dist
+
         dist.barrier()
         dist.destroy_process_group()
 

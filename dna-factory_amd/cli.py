@@ -270,6 +270,16 @@ class _NoClose:
 def generate_population(args):
     from . import population as pop
 
+    try:
+        devices = [int(d) for d in args.devices.split(",") if d.strip() != ""]
+    except ValueError:
+        raise SystemExit("--devices takes comma-separated GPU ids, got %r" % args.devices)
+    if not devices or min(devices) < 0:
+        raise SystemExit("--devices needs at least one GPU id (>= 0), got %r" % args.devices)
+    if not args.host_bgzf and args.compression_level != 6:
+        # the reference hands -z to zlib; the on-GPU encoder has one setting (about zlib -6's size)
+        print("note: -z %d does not apply to the on-GPU BGZF encoder (output is about as small as zlib -6); "
+              "use --host-bgzf to compress with zlib at that level like the reference" % args.compression_level, flush=True)
     t_start = time.time()
     seed = args.seed if args.seed is not None else int(datetime.now().strftime("%H%M%S"))  # pop_factory.py:235
     numpy.random.seed(seed)
@@ -320,7 +330,6 @@ def generate_population(args):
         raise Exception("No SNPs to Process! Exiting.")
     st = pop.build_samples(groups, args.control_size, args.size, args.male_odds, outdir, offset=args.offset or 0)
     header = pop.vcf_header(st.person_id)
-    devices = [int(d) for d in args.devices.split(",") if d != ""]
     mt_state = None
     if args.rng == "mt19937":
         # the reference's worker forks here and keeps drawing from the parent's numpy stream (pop_factory.py:432-434)

@@ -13,6 +13,7 @@
 #include "mt_jump.h"
 #include "mt_kernels.hip.h"
 
+#include <cctype>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -446,10 +447,17 @@ int dnaf_set_snps(dnaf_ctx* c, const dnaf_snp_table* t)
     c->h_text_off[(size_t)n] = off;
     const uint64_t pbytes = n ? t->prefix_off[n] - pbase : 0;
     if (pbytes && !t->prefix_bytes) return fail(c, DNAF_ERR_BAD_ARG, "dnaf_set_snps: prefix_bytes is NULL");
-    HIP_TRY(c, hipMalloc((void**)&c->d_recs, (n ? n : 1) * sizeof(RowRec)));
-    HIP_TRY(c, hipMalloc((void**)&c->d_prefix, pbytes ? pbytes : 1));
-    if (n) HIP_TRY(c, hipMemcpy(c->d_recs, recs.data(), n * sizeof(RowRec), hipMemcpyHostToDevice));
-    if (pbytes) HIP_TRY(c, hipMemcpy(c->d_prefix, t->prefix_bytes + pbase, pbytes, hipMemcpyHostToDevice));
+    {
+        hipError_t e = hipMalloc((void**)&c->d_recs, (n ? n : 1) * sizeof(RowRec));
+        if (e == hipSuccess) e = hipMalloc((void**)&c->d_prefix, pbytes ? pbytes : 1);
+        if (e == hipSuccess && n) e = hipMemcpy(c->d_recs, recs.data(), n * sizeof(RowRec), hipMemcpyHostToDevice);
+        if (e == hipSuccess && pbytes) e = hipMemcpy(c->d_prefix, t->prefix_bytes + pbase, pbytes, hipMemcpyHostToDevice);
+        if (e != hipSuccess) { // no half-loaded table is left behind
+            dev_free(c->d_recs);
+            dev_free(c->d_prefix);
+            return fail(c, e == hipErrorOutOfMemory ? DNAF_ERR_OOM : DNAF_ERR_HIP, "dnaf_set_snps: %s", hipGetErrorString(e));
+        }
+    }
     c->n_rows = n;
     c->have_snps = true;
     return DNAF_OK;
@@ -549,8 +557,13 @@ static int mt_prepare_states(dnaf_ctx* c, uint64_t lo, uint64_t n, uint64_t D)
         HIP_TRY(c, hipStreamSynchronize(c->stream));
         uint32_t *a = nullptr, *b = nullptr;
         HIP_TRY(c, hipMalloc((void**)&a, n * 624 * sizeof(uint32_t)));
-        HIP_TRY(c, hipMalloc((void**)&b, n * 624 * sizeof(uint32_t)));
-        if (c->mt_valid && c->mt_n) HIP_TRY(c, hipMemcpy(a, c->d_mt_states, c->mt_n * 624 * sizeof(uint32_t), hipMemcpyDeviceToDevice));
+        hipError_t e2 = hipMalloc((void**)&b, n * 624 * sizeof(uint32_t));
+        if (e2 == hipSuccess && c->mt_valid && c->mt_n) e2 = hipMemcpy(a, c->d_mt_states, c->mt_n * 624 * sizeof(uint32_t), hipMemcpyDeviceToDevice);
+        if (e2 != hipSuccess) { // nothing allocated here outlives the failure
+            (void)hipFree(a);
+            if (b) (void)hipFree(b);
+            return fail(c, e2 == hipErrorOutOfMemory ? DNAF_ERR_OOM : DNAF_ERR_HIP, "mt_prepare_states: %s", hipGetErrorString(e2));
+        }
         dev_free(c->d_mt_states);
         dev_free(c->d_mt_tmp);
         c->d_mt_states = a;
@@ -943,14 +956,19 @@ int dnaf_bgzf_compress(dnaf_ctx* c, uint32_t flags, uint64_t* n_bytes)
         dev_free(c->d_fast);
         dev_free(c->d_todo);
         c->blocks_cap = 0;
-        HIP_TRY(c, hipMalloc((void**)&c->d_todo, ((uint64_t)nb + 1) * sizeof(uint32_t)));
-        HIP_TRY(c, hipMalloc((void**)&c->d_member_row, (uint64_t)nb * sizeof(uint32_t)));
-        HIP_TRY(c, hipMalloc((void**)&c->d_fast, (uint64_t)nb));
-        HIP_TRY(c, hipMalloc((void**)&c->d_crcs, (uint64_t)nb * sizeof(uint32_t)));
-        HIP_TRY(c, hipMalloc((void**)&c->d_large, ((uint64_t)nb + 1) * sizeof(uint32_t)));
-        HIP_TRY(c, hipMalloc((void**)&c->d_sizes, (uint64_t)nb * sizeof(uint32_t)));
-        HIP_TRY(c, hipMalloc((void**)&c->d_thread_bits, (uint64_t)nb * dnaf::BGZF_THREADS * sizeof(uint16_t)));
-        HIP_TRY(c, hipMalloc((void**)&c->d_offsets, ((uint64_t)nb + 1) * sizeof(uint64_t)));
+        hipError_t e = hipMalloc((void**)&c->d_todo, ((uint64_t)nb + 1) * sizeof(uint32_t));
+        if (e == hipSuccess) e = hipMalloc((void**)&c->d_member_row, (uint64_t)nb * sizeof(uint32_t));
+        if (e == hipSuccess) e = hipMalloc((void**)&c->d_fast, (uint64_t)nb);
+        if (e == hipSuccess) e = hipMalloc((void**)&c->d_crcs, (uint64_t)nb * sizeof(uint32_t));
+        if (e == hipSuccess) e = hipMalloc((void**)&c->d_large, ((uint64_t)nb + 1) * sizeof(uint32_t));
+        if (e == hipSuccess) e = hipMalloc((void**)&c->d_sizes, (uint64_t)nb * sizeof(uint32_t));
+        if (e == hipSuccess) e = hipMalloc((void**)&c->d_thread_bits, (uint64_t)nb * dnaf::BGZF_THREADS * sizeof(uint16_t));
+        if (e == hipSuccess) e = hipMalloc((void**)&c->d_offsets, ((uint64_t)nb + 1) * sizeof(uint64_t));
+        if (e != hipSuccess) { // all or nothing: a partial set is not kept
+            dev_free(c->d_todo); dev_free(c->d_member_row); dev_free(c->d_fast); dev_free(c->d_crcs);
+            dev_free(c->d_large); dev_free(c->d_sizes); dev_free(c->d_thread_bits); dev_free(c->d_offsets);
+            return fail(c, e == hipErrorOutOfMemory ? DNAF_ERR_OOM : DNAF_ERR_HIP, "dnaf_bgzf_compress: %s", hipGetErrorString(e));
+        }
         c->blocks_cap = nb;
     }
     dnaf::BgzfParams p;
@@ -1363,10 +1381,20 @@ int dnaf_parse_snps_json(const char* text, uint64_t n_bytes, uint64_t max_rows, 
         if (lit(", \"tuples\": {")) {
             while (true) {
                 if (na >= 4 || !lit("\"") || !str(alleles + (j * 4 + na) * allele_w, allele_w) || !lit(": ")) return DNAF_ERR_UNSUPPORTED;
+                // the number token is copied out first: the text need not be NUL-terminated
+                char num[48];
+                size_t nl = 0;
+                while (p + nl < end && nl + 1 < sizeof num && (isdigit((unsigned char)p[nl]) || p[nl] == '.' || p[nl] == '-' || p[nl] == '+' || p[nl] == 'e' || p[nl] == 'E')) ++nl;
+                if (nl == 0 || nl + 1 >= sizeof num) return DNAF_ERR_UNSUPPORTED;
+                memcpy(num, p, nl);
+                num[nl] = 0;
                 char* stop = nullptr;
-                cum[j * 4 + na] = strtod(p, &stop);
-                if (stop == p || stop > end) return DNAF_ERR_UNSUPPORTED;
-                p = stop;
+                cum[j * 4 + na] = strtod(num, &stop);
+                if (stop != num + nl) return DNAF_ERR_UNSUPPORTED;
+                p += nl;
+                // a key that repeats: json.loads (the reference's reader, pop_factory.py:126-133) keeps only the last one
+                for (uint32_t k = 0; k < na; ++k)
+                    if (!memcmp(alleles + (j * 4 + k) * allele_w, alleles + (j * 4 + na) * allele_w, allele_w)) return DNAF_ERR_UNSUPPORTED;
                 ++na;
                 if (lit(", ")) continue;
                 if (lit("}")) break;

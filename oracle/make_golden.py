@@ -251,9 +251,92 @@ def case_full_flow(pf_mod):
     dump("full_flow_120x400", pf.ordered_snps, spec, 20261, lines_mt, lines_ph, extra)
 
 
+def case_config1(pf_mod):
+    """BASELINE config 1 at its stated size through the UNMODIFIED reference: `pop_factory.py -s 100 -c 100 -x 100000
+    -f 0.01 -n 1` = PopulationFactory(num_processes=1, ...).generate_population(100, 100, 0.01, 100000, 6), with the
+    three things a test cannot otherwise fix pinned from outside: the wall clock the reference takes its numpy seed and
+    its ##filedate from (pop_factory.datetime frozen at 12:34:56 -> numpy.random.seed(123456), pop_factory.py:235),
+    python's `random` (seeded with the same number; the reference never seeds it), and Bio.bgzf.BgzfWriter (biopython
+    is not installed: a stand-in that hashes the text it is given -- parity is on the decompressed stream).
+    Only SHA-256 digests and sizes are stored (the VCF body alone is 83 MB)."""
+    import datetime as real_datetime
+    import hashlib
+
+    class FrozenDatetime(real_datetime.datetime):
+        @classmethod
+        def now(cls, tz=None):
+            return cls(2026, 10, 4, 12, 34, 56)
+
+    class HashingWriter:
+        digest = None
+        n_lines = 0
+        n_bytes = 0
+        first_body_line = None
+
+        def __init__(self, filename=None, mode="w", fileobj=None, compresslevel=6):
+            self.h = hashlib.sha256()
+
+        def write(self, text):
+            data = text.encode() if isinstance(text, str) else text
+            for line in data.splitlines(keepends=True):
+                if line.startswith(b"##filedate="):
+                    continue  # wall clock (SURVEY Q13)
+                if not line.startswith(b"#") and HashingWriter.first_body_line is None:
+                    HashingWriter.first_body_line = line[:120].decode()
+                self.h.update(line)
+                HashingWriter.n_lines += 1
+                HashingWriter.n_bytes += len(line)
+
+        def __enter__(self):
+            return self
+
+        def __exit__(self, *a):
+            HashingWriter.digest = self.h.hexdigest()
+            return False
+
+    seed = 123456
+    tmp = tempfile.mkdtemp(prefix="dnaf_config1_")
+    old_dt, old_writer = pf_mod.datetime, pf_mod.bgzf.BgzfWriter
+    pf_mod.datetime = FrozenDatetime
+    pf_mod.bgzf.BgzfWriter = HashingWriter
+    random.seed(seed)
+    cwd = os.getcwd()
+    os.chdir(REF)  # -p deleterious.yml is cwd-relative (SURVEY Q10)
+    try:
+        pf = pf_mod.PopulationFactory(num_processes=1, generate_snps=True, male_odds=0.5, deleterious_config="deleterious.yml",
+                                      output_path=tmp)
+        pf.generate_population(100, 100, 0.01, 100000, 6)
+    finally:
+        os.chdir(cwd)
+        pf_mod.datetime, pf_mod.bgzf.BgzfWriter = old_dt, old_writer
+
+    def sha(path, opener=open):
+        with opener(path, "rb") as f:
+            data = f.read()
+        return {"sha256": hashlib.sha256(data).hexdigest(), "bytes": len(data)}
+
+    doc = {
+        "command": "pop_factory.py -s 100 -c 100 -x 100000 -f 0.01 -n 1  (reference, unmodified; clock frozen at 12:34:56)",
+        "numpy_seed": seed, "python_random_seed": seed,
+        "vcf_without_filedate": {"sha256": HashingWriter.digest, "bytes": HashingWriter.n_bytes, "lines": HashingWriter.n_lines,
+                                 "first_body_line_head": HashingWriter.first_body_line},
+        "population_fam": sha(os.path.join(tmp, "population.fam")),
+        "pop_deleterious_txt": sha(os.path.join(tmp, "pop_deleterious.txt")),
+        "deleterious_json": sha(os.path.join(tmp, "deleterious.json")),
+        "snps_json_decompressed": sha(os.path.join(tmp, "snps.json.gz"), gzip.open),
+    }
+    path = os.path.join(GOLD, "config1_sha256.json")
+    with open(path, "w") as f:
+        json.dump(doc, f, indent=1)
+    print("wrote %s: %s" % (path, json.dumps(doc["vcf_without_filedate"])))
+
+
 def main():
     os.makedirs(GOLD, exist_ok=True)
     pf_mod = import_reference()
+    if "--only-config1" in sys.argv:
+        case_config1(pf_mod)
+        return
     # the reference's own known answers, test/unit/pop_factory_test.py:24-28
     t = make_snp(pf_mod, 100, "1", 50000, [("G", 0.70), ("A", 0.90), ("T", 1.0)])
     assert t.pick_allele_index(0.95) == 2 and t.pick_allele_index(0.4) == 0
@@ -262,6 +345,8 @@ def main():
     case_threshold_equality(pf_mod)
     case_ragged(pf_mod)
     case_full_flow(pf_mod)
+    if "--skip-config1" not in sys.argv:
+        case_config1(pf_mod)  # about a minute: the reference's own worker over 2x10^7 genotypes
 
 
 if __name__ == "__main__":

@@ -147,7 +147,9 @@ def _members(blob):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("n_rows,S", [(1, 1), (3, 0), (40, 333), (900, 2000), (64, 20000), (16, 61440 // 4)])
-def test_gpu_bgzf_inflates_to_the_text(capi, n_rows, S):
+def test_gpu_bgzf_inflates_to_the_text(capi, oracle, n_rows, S):
+    """What the members must inflate to is the ORACLE's text (the CPU restatement of the reference worker), not the
+    text the same GPU run produced."""
     from dna_factory_amd.rowgen import RowGenerator
 
     rs = np.random.RandomState(n_rows + S)
@@ -158,6 +160,9 @@ def test_gpu_bgzf_inflates_to_the_text(capi, n_rows, S):
         text, _, _ = g.generate(text=True, packed=False)
         blob, n_text = g.generate_bgzf()
         blob2, _ = g.generate_bgzf(reuse_tables=True)
+    sex, ctrl, off, ids = oracle.sample_arrays(samples)
+    want_text, _, _ = oracle.generate(oracle.snp_records(snps), sex, ctrl, off, ids, rng_mode=oracle.RNG_PHILOX, seed=3)
+    assert text.tobytes() == want_text
     raw = blob.tobytes()
     assert n_text == len(text)
     assert gzip.decompress(raw) == text.tobytes()  # checks every member's CRC-32 and ISIZE too
@@ -303,20 +308,21 @@ def _sorted_case(S, n, seed, min_maf=0.01):
 @pytest.mark.gpu
 @pytest.mark.parametrize("S,n", [(2, 9000), (3, 7000), (17, 3000), (700, 400), (950, 300), (2000, 300), (15360, 40),
                                  (20000, 120), (20001, 60), (100003, 12)])
-def test_gtz_members_inflate_to_the_text(capi, S, n):
+def test_gtz_members_inflate_to_the_text(capi, oracle, S, n):
     """Rows sorted as the CLI sorts them (autosomes, then MT / X / Y): most members are made from the genotype
-    matrix, the ones that touch other chromosome classes from the text; every one must inflate to the text."""
+    matrix, the ones that touch other chromosome classes from the text; every one must inflate to the text -- the
+    ORACLE's text for these rows, not this run's own."""
     from dna_factory_amd.rowgen import RowGenerator
 
     tb, st = _sorted_case(S, n, seed=S + n)
     with RowGenerator(device=0, seed=11) as g:
         g.set_samples(st)
         g.set_snps(tb)
-        text, _, _ = g.generate(text=True, packed=False)
         blob, n_text = g.generate_bgzf()
         blob_again, _ = g.generate_bgzf(reuse_tables=True)
         blob_text, _ = g.generate_bgzf(text_domain=True)
-    want = text.tobytes()
+    sex, ctrl, doff, dids = oracle.sample_arrays_from_table(st.flags, st.forced_ids, st.carrier_off, st.carrier_idx)
+    want, _, _ = oracle.generate(oracle.table_records(tb), sex, ctrl, doff, dids, seed=11)
     assert n_text == len(want)
     for b in (blob, blob_again, blob_text):
         assert gzip.decompress(b.tobytes()) == want

@@ -212,10 +212,11 @@ def test_cli_chunk_restart_matches_the_reference_chunking(oracle, tmp_path):
 
 
 @pytest.mark.gpu
-def test_plink_bed_matches_the_vcf(tmp_path):
+def test_plink_bed_matches_the_vcf(oracle, tmp_path):
     """--plink: population.bed / .bim made on the GPU from the packed matrix agree, genotype by genotype, with the
-    VCF of the same run under PLINK's import rules (A1 = ALT, A2 = REF; haploid calls stored as homozygous, '.' as
-    missing).  plink itself is not installed here: parity with its own converter is unpinned."""
+    VCF body the ORACLE produces for the run's inputs (which the run's own VCF must equal) under PLINK's import rules
+    (A1 = ALT, A2 = REF; haploid calls stored as homozygous, '.' as missing).  plink itself is not installed here:
+    parity with its own converter is unpinned."""
     import gzip
 
     import numpy as np
@@ -229,7 +230,9 @@ def test_plink_bed_matches_the_vcf(tmp_path):
     assert raw[:3] == bytes([0x6C, 0x1B, 0x01])
     bed = np.frombuffer(raw[3:], dtype=np.uint8).reshape(3000, (S + 3) // 4)
     bim = [l.split("\t") for l in (out / "population.bim").read_text().splitlines()]
+    want_body, _ = _expected_body(str(out), 5, oracle)
     lines = [l for l in gzip.open(out / "population.vcf.gz", "rt").read().splitlines() if not l.startswith("#")]
+    assert ("\n".join(lines) + "\n").encode() == want_body  # the expectations below are the oracle's cells
     assert len(lines) == len(bim) == 3000
     fam = (out / "population.fam").read_text().splitlines()
     assert len(fam) == S
@@ -268,3 +271,78 @@ def test_two_shards_give_the_same_vcf_and_bed(tmp_path):
     assert (one / "population.bed").read_bytes() == (two / "population.bed").read_bytes()
     assert (one / "population.bim").read_bytes() == (two / "population.bim").read_bytes()
     assert not [f for f in os.listdir(two) if "shard" in f]
+
+
+# ---- BASELINE config 1 at its stated size, against the unmodified reference CLI (tests/golden/config1_sha256.json) ----
+def _config1_golden():
+    with open(os.path.join(REPO, "tests", "golden", "config1_sha256.json")) as f:
+        return json.load(f)
+
+
+def _sha(data):
+    import hashlib
+
+    return {"sha256": hashlib.sha256(data).hexdigest(), "bytes": len(data)}
+
+
+def test_config1_host_files_equal_the_reference(cli, tmp_path):
+    """`-s 100 -c 100 -x 100000 -f 0.01` at the reference's seeds (numpy 123456 from its frozen clock, python random the
+    same): snps.json.gz, deleterious.json, population.fam and pop_deleterious.txt of this build hash to what the
+    unmodified reference wrote (oracle/make_golden.py case_config1).  Host side only: runs without a GPU."""
+    import random
+
+    from dna_factory_amd import population as pop
+
+    gold = _config1_golden()
+    seed = gold["numpy_seed"]
+    np.random.seed(seed)
+    random.seed(gold["python_random_seed"])
+    out = str(tmp_path) + os.path.sep
+    tb = pop.sort_snp_table(pop.generate_snp_table(100000, min_maf=0.01))
+    pop.write_snps_file(tb, out + "snps.json.gz")
+    groups = pop.pick_deleterious(tb, os.path.join(REPO, "deleterious.yml"))
+    pop.write_deleterious_json(groups, out + "deleterious.json")
+    pop.build_samples(groups, 100, 100, 0.5, out, offset=0)
+    assert _sha(gzip.open(out + "snps.json.gz", "rb").read()) == gold["snps_json_decompressed"]
+    assert _sha(open(out + "deleterious.json", "rb").read()) == gold["deleterious_json"]
+    assert _sha(open(out + "population.fam", "rb").read()) == gold["population_fam"]
+    assert _sha(open(out + "pop_deleterious.txt", "rb").read()) == gold["pop_deleterious_txt"]
+
+
+@pytest.mark.gpu
+def test_config1_whole_output_directory_equals_the_reference(cli, tmp_path):
+    """BASELINE config 1 end to end: `pop_factory.py -s 100 -c 100 -x 100000 -f 0.01 -n 1 --rng mt19937 --seed 123456`
+    writes the VCF (200 samples x 100,000 SNPs, every byte but the ##filedate line) and the four side files of the
+    unmodified reference run at the same seeds."""
+    gold = _config1_golden()
+    out = str(tmp_path / "c1")
+    p = _run_cli(["-s", "100", "-c", "100", "-x", "100000", "-f", "0.01", "-n", "1", "--rng", "mt19937", "--seed",
+                  str(gold["numpy_seed"]), "--outdir", out])
+    assert p.returncode == 0, p.stderr[-3000:]
+    import hashlib
+
+    h, n_bytes, n_lines, first = hashlib.sha256(), 0, 0, None
+    with gzip.open(os.path.join(out, "population.vcf.gz"), "rb") as f:
+        for line in f:
+            if line.startswith(b"##filedate="):
+                continue
+            if first is None and not line.startswith(b"#"):
+                first = line[:120].decode()
+            h.update(line)
+            n_bytes += len(line)
+            n_lines += 1
+    want = gold["vcf_without_filedate"]
+    assert first == want["first_body_line_head"]
+    assert (n_lines, n_bytes) == (want["lines"], want["bytes"])
+    assert h.hexdigest() == want["sha256"]
+    assert _sha(gzip.open(os.path.join(out, "snps.json.gz"), "rb").read()) == gold["snps_json_decompressed"]
+    for name, key in (("deleterious.json", "deleterious_json"), ("population.fam", "population_fam"),
+                      ("pop_deleterious.txt", "pop_deleterious_txt")):
+        assert _sha(open(os.path.join(out, name), "rb").read()) == gold[key], name
+
+
+def test_cli_rejects_an_empty_device_list(tmp_path):
+    r = _run_cli(["-s", "1", "-c", "1", "-x", "10", "--devices", "", "--outdir", str(tmp_path / "d")])
+    assert r.returncode != 0 and "--devices" in (r.stderr + r.stdout)
+    r = _run_cli(["-s", "1", "-c", "1", "-x", "10", "--devices", "0,x", "--outdir", str(tmp_path / "e")])
+    assert r.returncode != 0 and "--devices" in (r.stderr + r.stdout)

@@ -18,9 +18,9 @@ import statistics
 
 def per_launch(path, counter):
     vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(path))
-            if "rowgen_kernel" in r["Kernel_Name"] and r["Counter_Name"] == counter]
+            if ("rowrun_kernel" in r["Kernel_Name"] or "rowgen_kernel" in r["Kernel_Name"]) and r["Counter_Name"] == counter]
     if not vals:
-        raise SystemExit("no %s rows for rowgen_kernel in %s" % (counter, path))
+        raise SystemExit("no %s rows for the row kernel in %s" % (counter, path))
     return statistics.mean(vals), len(vals)
 
 
@@ -36,7 +36,13 @@ def main():
     a = ap.parse_args()
     w_kib, nw = per_launch(a.write_csv, "WRITE_SIZE")
     f_kib, nf = per_launch(a.fetch_csv, "FETCH_SIZE")
+    import sys
+
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+
     doc = {
+        "kernel_source_sha16": bench.kernel_source_hash(),  # bench.py reports the figure only for these very sources
         "samples": a.samples, "tile_rows": a.tile_rows, "what": a.what,
         "write_bytes_per_launch": w_kib * 1024, "fetch_bytes_per_launch_raw": f_kib * 1024,
         "fetch_bytes_per_launch_corrected": 2 * f_kib * 1024,
