@@ -28,6 +28,15 @@
 using dnaf::GenParams;
 using dnaf::RowRec;
 
+// Workgroups of rowrun_kernel per CU, capped through unused dynamic LDS: 12,288 static + 41,000 pad = 3 workgroups
+// (12 waves) per CU instead of the 6 its registers allow.  The kernel is bound by its vector-instruction count and three
+// waves per SIMD cover the instruction latencies; with fewer waves in flight each wave's consecutive text stores are closer
+// in time, so fewer 128-byte lines that two of them share leave the L2 half-written -- measured on boxes in their slow
+// state: 4.35 ms per launch at 6 workgroups per CU, 4.16 at 4, 4.13 at 3, 4.35 at 2 (profiles/r02_occupancy_sweep.txt).
+#ifndef DNAF_RUN_LDS_PAD_DEFAULT
+#define DNAF_RUN_LDS_PAD_DEFAULT 41000
+#endif
+
 struct dnaf_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -125,6 +134,7 @@ struct dnaf_ctx {
     bool force_segments = false;     // DNAF_FORCE_SEGMENTS=1: always the segment form of the kernel (A/B runs, tests)
     uint64_t min_run_waves = 8192;   // fewer runs than this and long rows: the segment form fills the GPU better
     uint32_t force_rpw = 0;          // DNAF_ROWS_PER_WAVE: rows per wave of the line-owning form (tests)
+    uint32_t run_lds_pad = DNAF_RUN_LDS_PAD_DEFAULT; // unused dynamic LDS per workgroup of rowrun_kernel: caps the workgroups per CU
 };
 
 static const size_t MAX_TIMED = 4096;
@@ -192,6 +202,7 @@ int dnaf_create(int device, dnaf_ctx** out)
     }
     if (const char* s = getenv("DNAF_FORCE_SEGMENTS")) c->force_segments = atoi(s) != 0;
     if (const char* s = getenv("DNAF_MIN_RUN_WAVES")) c->min_run_waves = strtoull(s, nullptr, 10);
+    if (const char* s = getenv("DNAF_RUN_LDS_PAD")) c->run_lds_pad = (uint32_t)std::min<unsigned long long>(strtoull(s, nullptr, 10), 48u << 10);
     if (const char* s = getenv("DNAF_ROWS_PER_WAVE")) c->force_rpw = (uint32_t)std::min<unsigned long long>(strtoull(s, nullptr, 10), 1u << 20);
     if (const char* s = getenv("DNAF_SEG_ITERS")) {
         int v = atoi(s);
@@ -738,9 +749,10 @@ int dnaf_generate(dnaf_ctx* c, uint64_t row_begin, uint64_t n_rows, uint32_t wha
     if (rec) HIP_TRY(c, hipEventRecord(c->evs[2 * c->n_timed], c->stream));
     const dim3 grid((uint32_t)blocks), block(256);
     if (use_runs) {
-        if (what == (DNAF_OUT_TEXT | DNAF_OUT_PACKED)) hipLaunchKernelGGL((dnaf::rowrun_kernel<true, true>), grid, block, 0, c->stream, p);
-        else if (what == DNAF_OUT_TEXT) hipLaunchKernelGGL((dnaf::rowrun_kernel<true, false>), grid, block, 0, c->stream, p);
-        else hipLaunchKernelGGL((dnaf::rowrun_kernel<false, true>), grid, block, 0, c->stream, p);
+        const uint32_t pad = c->run_lds_pad;
+        if (what == (DNAF_OUT_TEXT | DNAF_OUT_PACKED)) hipLaunchKernelGGL((dnaf::rowrun_kernel<true, true>), grid, block, pad, c->stream, p);
+        else if (what == DNAF_OUT_TEXT) hipLaunchKernelGGL((dnaf::rowrun_kernel<true, false>), grid, block, pad, c->stream, p);
+        else hipLaunchKernelGGL((dnaf::rowrun_kernel<false, true>), grid, block, pad, c->stream, p);
     } else if (what == (DNAF_OUT_TEXT | DNAF_OUT_PACKED)) hipLaunchKernelGGL((dnaf::rowgen_kernel<true, true>), grid, block, 0, c->stream, p);
     else if (what == DNAF_OUT_TEXT) hipLaunchKernelGGL((dnaf::rowgen_kernel<true, false>), grid, block, 0, c->stream, p);
     else hipLaunchKernelGGL((dnaf::rowgen_kernel<false, true>), grid, block, 0, c->stream, p);

@@ -23,6 +23,9 @@
 #pragma once
 #include "rowgen_kernels.hip.h"
 
+#ifndef DNAF_RUN_TRIPS
+#define DNAF_RUN_TRIPS 2
+#endif
 #ifndef DNAF_RUN_BOUNDS
 // No register limits: the kernel is bound by its vector-instruction count, not by latency, and capping it at 64 VGPRs /
 // 80 SGPRs (8 waves per SIMD) makes hipcc re-materialise scalars in the hot loop (measured: 1 % slower than 6 workgroups per CU)
@@ -321,56 +324,93 @@ __device__ __forceinline__ bool run_row_biallelic(const SegCtx& c, uint32_t skip
     // scalar registers; the text address likewise is a wave-uniform base plus the lane's fixed offset
     const uint64_t pl = (uint64_t)PHILOX_M0 * (2u * lane);
     const uint64_t M = PHILOX_M0, M128 = (uint64_t)PHILOX_M0 * 128u;
-    if (skipc) {
-        // the first two trips on their own: the first one clipped at the line boundary, the second so that the
-        // two-trip passes below start on a multiple of 128 groups (chunks of 1024 are then never straddled)
-        uint32_t pk0 = group_code(pl, 0, M, rc, keys, c.t0), pk1 = group_code(pl, M128, M128 + M, rc, keys, c.t0);
-        if (c.frow) { pk0 = force_code(c, pk0, lane); pk1 = force_code(c, pk1, 64u + lane); }
+    constexpr uint32_t T = DNAF_RUN_TRIPS; // whole trips per pass = KiB per block of text stores
+    uint64_t off = 0;                      // M0 * 2 * gb, the wave's share of the first-round products
+    const uint32_t tl = 16u * lane;
+    // one whole trip at gb, stored at once (clip > 0: only the bytes from cell-stream offset clip on)
+    auto single = [&](uint32_t clip) {
+        uint32_t pk = group_code(pl, off, off + M, rc, keys, c.t0);
+        if (c.frow) pk = force_code(c, pk, gb + lane);
         if (TEXT) {
-            const u32x4_t w0 = c.lut[pk0], w1 = c.lut[pk1];
-            store16_from(c.cells, 16u * lane, w0, skipc);
-            store_unaligned<16>(c.cells + 1024u + 16u * lane, &w1);
+            const u32x4_t w = c.lut[pk];
+            if (clip) store16_from(c.cells, 16u * (gb + lane), w, clip);
+            else store_unaligned<16>(c.cells + 16ull * (gb + lane), &w);
         }
-        if (PACKED) { c.stage[lane] = (uint8_t)pk0; c.stage[64u + lane] = (uint8_t)pk1; }
-        gb = 128u;
+        if (PACKED) c.stage[(gb + lane) & (PK_STAGE - 1u)] = (uint8_t)pk;
+        gb += 64u; off += M128;
+        if (PACKED && CHUNKED && (gb & 1023u) == 0u) { flush_chunk(c, flushed, lane); ++flushed; }
+    };
+    if (skipc) {
+        // the run's first row: its first trip is clipped at the line boundary; T trips on their own keep the passes below
+        // on multiples of 64 T groups (a 1024-group chunk of packed bytes is then never straddled)
+        single(skipc);
+        for (uint32_t t = 1; t < T && gb + 64u <= g_fast; ++t) single(0u);
     }
     {
-        uint64_t off = (uint64_t)PHILOX_M0 * (2u * gb);
         gptr_t tb = uniform_ptr(c.cells + 16ull * gb);
-        const uint32_t tl = 16u * lane;
         LDS_PTR(uint8_t) sp = c.stage + ((gb + lane) & (PK_STAGE - 1u));
-        // Two trips per pass, software-pipelined: the cells looked up in one pass are stored in the next, so the
-        // LDS read flies under the following Philox rounds (the stores address the previous pass).
-        if (gb + 128u <= g_fast) {
-            u32x4_t w0 = {0, 0, 0, 0}, w1 = {0, 0, 0, 0};
+        // T trips per pass, software-pipelined: the cells looked up in one pass are stored in the next, so the LDS reads fly
+        // under the following Philox rounds.  The T KiB of a pass leave in back-to-back stores: a 128-byte line that two
+        // stores each cover a part of is written twice, and when the two parts are a pass apart in time (microseconds) the
+        // first has left the L2 by then -- HBM sees two partial writes.  The longer the blocks, the fewer such lines
+        // (tools/placement_study.hip, k_text_own with s_sleep: 1 KiB blocks cost 13 % of the store rate).
+        if (gb + 64u * T <= g_fast) {
+            u32x4_t w[T];
+#pragma unroll
+            for (uint32_t t = 0; t < T; ++t) w[t] = u32x4_t{0, 0, 0, 0};
             auto pass = [&](bool first) {
-                uint32_t pk0 = group_code(pl, off, off + M, rc, keys, c.t0);
-                uint32_t pk1 = group_code(pl, off + M128, off + M128 + M, rc, keys, c.t0);
-                if (c.frow) { pk0 = force_code(c, pk0, gb + lane); pk1 = force_code(c, pk1, gb + 64u + lane); } // wave-uniform
-                if (TEXT) {
-                    if (!first) { store16_global(tb - 2048 + tl, w0); store16_global(tb - 1024 + tl, w1); }
-                    w0 = c.lut[pk0];
-                    w1 = c.lut[pk1];
+                uint32_t pk[T];
+#pragma unroll
+                for (uint32_t t = 0; t < T; ++t) pk[t] = group_code(pl, off + t * M128, off + t * M128 + M, rc, keys, c.t0);
+                if (c.frow) { // wave-uniform
+#pragma unroll
+                    for (uint32_t t = 0; t < T; ++t) pk[t] = force_code(c, pk[t], gb + 64u * t + lane);
                 }
-                if (PACKED) { sp[0] = (uint8_t)pk0; sp[64] = (uint8_t)pk1; }
-                gb += 128u; off += 2u * M128; tb += 2048; sp += 128;
+                if (TEXT) {
+                    if (!first) {
+#pragma unroll
+                        for (uint32_t t = 0; t < T; ++t) store16_global(tb - 1024 * (int)(T - t) + tl, w[t]);
+                    }
+#pragma unroll
+                    for (uint32_t t = 0; t < T; ++t) w[t] = c.lut[pk[t]];
+                }
+                if (PACKED) {
+#pragma unroll
+                    for (uint32_t t = 0; t < T; ++t) sp[64u * t] = (uint8_t)pk[t];
+                }
+                gb += 64u * T; off += T * M128; tb += 1024 * T; sp += 64 * T;
                 if (PACKED && (gb & 1023u) == 0u) { // wave-uniform
                     if (CHUNKED) { flush_chunk(c, flushed, lane); ++flushed; }
                     if ((gb & (PK_STAGE - 1u)) == 0u) sp -= PK_STAGE;
                 }
             };
             pass(true);
-            while (gb + 128u <= g_fast) pass(false);
-            if (TEXT) { store16_global(tb - 2048 + tl, w0); store16_global(tb - 1024 + tl, w1); }
-        }
-        for (; gb + 64u <= g_fast; gb += 64u, off += M128, tb += 1024, sp += 64) {
-            uint32_t pk = group_code(pl, off, off + M, rc, keys, c.t0);
-            if (c.frow) pk = force_code(c, pk, gb + lane);
+            while (gb + 64u * T <= g_fast) pass(false);
             if (TEXT) {
-                const u32x4_t w = c.lut[pk];
-                store16_global(tb + tl, w);
+#pragma unroll
+                for (uint32_t t = 0; t < T; ++t) store16_global(tb - 1024 * (int)(T - t) + tl, w[t]);
             }
-            if (PACKED) *sp = (uint8_t)pk;
+        }
+        // the whole trips that are left (fewer than T): one more block
+        {
+            u32x4_t w[T];
+            uint32_t n = 0;
+#pragma unroll
+            for (uint32_t t = 0; t + 1 < T; ++t) {
+                if (gb + 64u <= g_fast) { // wave-uniform
+                    uint32_t pk = group_code(pl, off, off + M, rc, keys, c.t0);
+                    if (c.frow) pk = force_code(c, pk, gb + lane);
+                    if (TEXT) w[t] = c.lut[pk];
+                    if (PACKED) c.stage[(gb + lane) & (PK_STAGE - 1u)] = (uint8_t)pk;
+                    gb += 64u; off += M128; n = t + 1;
+                    if (PACKED && CHUNKED && (gb & 1023u) == 0u) { flush_chunk(c, flushed, lane); ++flushed; }
+                }
+            }
+            if (TEXT) {
+#pragma unroll
+                for (uint32_t t = 0; t + 1 < T; ++t)
+                    if (t < n) store_unaligned<16>(c.cells + 16ull * (gb - 64u * (n - t) + lane), &w[t]);
+            }
         }
     }
     // the last, partly filled trip; its last group holds the row's last sample (newline, maybe < 4 samples).  Its idle

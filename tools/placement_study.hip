@@ -281,7 +281,8 @@ __global__ __launch_bounds__(256) void k_text_ring3(uint8_t* text, uint8_t* pack
 //  MODE 0: wave j stores the bytes of row j, [R_j, R_j+1), in 16-byte pieces at the row's own phase (the row kernel today)
 //  MODE 1: wave j stores the LINES [ceil128(R_j), ceil128(R_j+1)) in aligned 16-byte pieces
 //  MODE 2: the same range as MODE 1 but in 16-byte pieces at the row's phase (R_j mod 16), the < 16 bytes at either end by byte stores
-template <int MODE>
+//  SLEEP: s_sleep between a wave's stores, so that they are as far apart in time as the row kernel's (one trip = 1.4 us)
+template <int MODE, int SLEEP = 0>
 __global__ __launch_bounds__(256) void k_text_own(uint8_t* text, uint64_t row_bytes, uint64_t n_rows)
 {
     const uint32_t lane = threadIdx.x & 63;
@@ -300,9 +301,50 @@ __global__ __launch_bounds__(256) void k_text_own(uint8_t* text, uint64_t row_by
     for (; o + 16 <= e; o += 1024) {
         v.x += lane;
         __builtin_memcpy(text + o, &v, 16);
+        if (SLEEP) __builtin_amdgcn_s_sleep(SLEEP);
     }
     // the last < 16 bytes: the lane whose piece would cross e stores them byte by byte
     if (o < e) for (uint64_t q = o; q < e; ++q) text[q] = (uint8_t)v.y;
+}
+
+// k_text_own<2> (a wave per row, owned lines) with the text realigned through a per-wave LDS ring: every trip's KiB is
+// written to the ring at its natural, 16-byte aligned place and read back SHIFTED (one byte-unaligned ds_read_b128 per lane),
+// so that every global store instruction covers 8 whole 128-byte lines.  No vector ALU work for the shift.
+template <int SLEEP>
+__global__ __launch_bounds__(256) void k_text_own_ring(uint8_t* text, uint64_t row_bytes, uint64_t n_rows)
+{
+    __shared__ __attribute__((aligned(128))) uint8_t ring_all[4][2048 + 128 + 128];
+    const uint32_t lane = threadIdx.x & 63;
+    const uint64_t row = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= n_rows) return;
+    uint8_t* ring = ring_all[threadIdx.x >> 6];
+    const uint64_t r0 = row * row_bytes, r1 = r0 + row_bytes;
+    const uint64_t b = (r0 + 127) & ~127ull, e = (r1 + 127) & ~127ull;   // the lines this wave owns
+    u32x4_a1 v = {0x09302F30u, 0x09302F31u, 0x09312F30u, 0x09312F31u};
+    // the wave's data stream starts at s (first piece at the row's phase at or after b), as in k_text_own<2>
+    const uint64_t s = b + ((r0 - b) & 15u);
+    if (lane < (uint32_t)(s - b)) text[b + lane] = (uint8_t)v.x;
+    // stream offset t: trip k, lane i holds bytes [1024 k + 16 i, +16); output windows are aligned: window k covers stream
+    // offsets [a + 1024 (k-1), a + 1024 k) with a = (128 - (s & 127)) & 127 -- but here s - b < 16, so the first line is b itself:
+    const uint32_t a = (uint32_t)((128u - (uint32_t)(s & 127u)) & 127u);
+    const uint32_t mirror = lane < 8u ? 2048u + 16u * lane : 2048u + 128u + 16u * (lane & 7u);
+    const uint32_t rd_e = a + 16u * lane, rd_o = 1024u + rd_e;
+    uint64_t o = s + 16ull * lane;          // address of this lane's natural piece
+    uint64_t wdst = s + a + 16ull * lane;   // address of this lane's piece of the next aligned window
+    uint32_t k = 0;
+    for (; o + 16 <= e + 1024; o += 1024, ++k) { // one trip beyond the data flushes the ring's last window
+        const bool have = o + 16 <= e;
+        v.x += lane;
+        if (have) *reinterpret_cast<u32x4*>(ring + (k & 1u) * 1024u + 16u * lane) = v;
+        if (have && !(k & 1u)) *reinterpret_cast<u32x4*>(ring + mirror) = v;
+        if (k == 0) { if (16u * lane < a) __builtin_memcpy(text + o, &v, 16); } // head: the bytes before the first aligned line
+        else if (wdst + 16 <= e) {
+            const u32x4_a1 w = *reinterpret_cast<const u32x4_a1*>(ring + ((k & 1u) ? rd_e : rd_o));
+            *reinterpret_cast<u32x4*>(text + wdst) = w;
+            wdst += 1024;
+        }
+        if (SLEEP) __builtin_amdgcn_s_sleep(SLEEP);
+    }
 }
 
 static GenParams P;
@@ -639,6 +681,30 @@ int main(int argc, char** argv)
             const uint64_t rb2 = 80128;
             const float t3 = ev_time([&] { hipLaunchKernelGGL(k_text_own<0>, dim3((uint32_t)((249000 + 3) / 4)), block, 0, stream, d_text, rb2, (uint64_t)249000); });
             printf("OWN rows of 80037 B, a wave per row: row bytes at row phase %.3f | owned lines, aligned pieces %.3f | owned lines, row-phase pieces %.3f | rows of 80128 B %.3f ms\n", t0, t1, t2, t3);
+            const float s0 = ev_time([&] { hipLaunchKernelGGL((k_text_own<0, 40>), grid, block, 0, stream, d_text, rb, nr); });
+            const float s1 = ev_time([&] { hipLaunchKernelGGL((k_text_own<1, 40>), grid, block, 0, stream, d_text, rb, nr); });
+            const float s2 = ev_time([&] { hipLaunchKernelGGL((k_text_own<2, 40>), grid, block, 0, stream, d_text, rb, nr); });
+            const float u1 = ev_time([&] { hipLaunchKernelGGL((k_text_own<1, 20>), grid, block, 0, stream, d_text, rb, nr); });
+            const float u2 = ev_time([&] { hipLaunchKernelGGL((k_text_own<2, 20>), grid, block, 0, stream, d_text, rb, nr); });
+            printf("OWN with s_sleep 40 between trips: row phase %.3f | aligned pieces %.3f | owned lines row-phase pieces %.3f ;  s_sleep 20: aligned %.3f row-phase %.3f ms\n", s0, s1, s2, u1, u2);
+            const float g0 = ev_time([&] { hipLaunchKernelGGL((k_text_own_ring<0>), grid, block, 0, stream, d_text, rb, nr); });
+            const float g20 = ev_time([&] { hipLaunchKernelGGL((k_text_own_ring<20>), grid, block, 0, stream, d_text, rb, nr); });
+            const float g40 = ev_time([&] { hipLaunchKernelGGL((k_text_own_ring<40>), grid, block, 0, stream, d_text, rb, nr); });
+            printf("OWN ring (aligned lines through LDS, unaligned ds_read_b128): no sleep %.3f | s_sleep 20 %.3f | s_sleep 40 %.3f ms\n", g0, g20, g40);
+            if (rep == 0) {
+                const size_t nchk = 128u << 20;
+                std::vector<uint8_t> h0(nchk), h1(nchk);
+                CK(hipMemsetAsync(d_text, 0, text_bytes, stream));
+                hipLaunchKernelGGL((k_text_own<2, 0>), grid, block, 0, stream, d_text, rb, nr);
+                CK(hipMemcpyAsync(h0.data(), d_text + (4ull << 30), nchk, hipMemcpyDeviceToHost, stream));
+                CK(hipMemsetAsync(d_text, 0, text_bytes, stream));
+                hipLaunchKernelGGL((k_text_own_ring<0>), grid, block, 0, stream, d_text, rb, nr);
+                CK(hipMemcpyAsync(h1.data(), d_text + (4ull << 30), nchk, hipMemcpyDeviceToHost, stream));
+                CK(hipStreamSynchronize(stream));
+                size_t bad = 0, first = 0, holes0 = 0, holes1 = 0;
+                for (size_t i = 0; i < nchk; ++i) { if (!h0[i]) ++holes0; if (!h1[i]) ++holes1; if ((h0[i] != 0) != (h1[i] != 0)) { if (!bad) first = i; ++bad; } }
+                printf("OWN ring coverage check: %zu bytes written by one kernel only (first at %zu); unwritten %zu vs %zu\n", bad, first, holes0, holes1);
+            }
         }
         for (int k = 0; k < K; ++k) {
             char tag[64];
