@@ -99,7 +99,9 @@ __device__ __forceinline__ RowConst make_row_const(const SegCtx& c)
 // and the kernel is bound by exactly this count (SQ_ACTIVE_INST_VALU x 4 cycles = 100 % of the SIMD cycles).
 //   P    = M0 * 2 * lane, the lane's share of the first-round product (constant for the whole kernel)
 //   offa = M0 * 2 * gb, offb = offa + M0: the wave's share for the group's two blocks (scalar registers)
-// Temporaries are fixed registers (v40 .. v53): the products need aligned pairs whose halves are named one by one.
+// Temporaries are fixed registers (v40 .. v67): the products need aligned pairs whose halves are named one by one.  The two
+// blocks are interleaved instruction by instruction: two independent dependency chains per wave (the kernel runs at three
+// waves per SIMD, see DNAF_RUN_LDS_PAD_DEFAULT).
 struct RowKeys { uint32_t k02, k0[7], k1[7]; }; // k0 + r W0 for rounds 2 .. 9, k1 + r W1 for rounds 3 .. 9
 
 __device__ __forceinline__ RowKeys make_row_keys(uint32_t k0, uint32_t k1)
@@ -113,42 +115,79 @@ __device__ __forceinline__ RowKeys make_row_keys(uint32_t k0, uint32_t k1)
 
 #define DNAF_GROUP_ASM \
         "v_lshl_add_u64 v[40:41], %[P], 0, %[offb]\n\t" \
+        "v_lshl_add_u64 v[54:55], %[P], 0, %[offa]\n\t" \
         "v_xor_b32 v46, %[x0], v41\n\t" \
+        "v_xor_b32 v60, %[x0], v55\n\t" \
         "v_mad_u64_u32 v[52:53], vcc, v46, %[m1], 0\n\t" \
+        "v_mad_u64_u32 v[66:67], vcc, v60, %[m1], 0\n\t" \
         "v_xor_b32 v44, %[x1], v53\n\t" \
+        "v_xor_b32 v58, %[x1], v67\n\t" \
         "v_xor_b32 v46, %[x2], v40\n\t" \
+        "v_xor_b32 v60, %[x2], v54\n\t" \
         "v_mad_u64_u32 v[40:41], vcc, v44, %[m0], 0\n\t" \
+        "v_mad_u64_u32 v[54:55], vcc, v58, %[m0], 0\n\t" \
         "v_mad_u64_u32 v[48:49], vcc, v46, %[m1], 0\n\t" \
+        "v_mad_u64_u32 v[62:63], vcc, v60, %[m1], 0\n\t" \
         "v_bitop3_b32 v44, v49, v52, %[k02] bitop3:0x96\n\t" \
+        "v_bitop3_b32 v58, v63, v66, %[k02] bitop3:0x96\n\t" \
         "v_xor_b32 v46, %[x3], v41\n\t" \
+        "v_xor_b32 v60, %[x3], v55\n\t" \
         "v_mad_u64_u32 v[50:51], vcc, v44, %[m0], 0\n\t" \
+        "v_mad_u64_u32 v[64:65], vcc, v58, %[m0], 0\n\t" \
         "v_mad_u64_u32 v[52:53], vcc, v46, %[m1], 0\n\t" \
+        "v_mad_u64_u32 v[66:67], vcc, v60, %[m1], 0\n\t" \
         "v_bitop3_b32 v44, v53, v48, %[k03] bitop3:0x96\n\t" \
+        "v_bitop3_b32 v58, v67, v62, %[k03] bitop3:0x96\n\t" \
         "v_bitop3_b32 v46, v51, v40, %[k13] bitop3:0x96\n\t" \
+        "v_bitop3_b32 v60, v65, v54, %[k13] bitop3:0x96\n\t" \
         "v_mad_u64_u32 v[40:41], vcc, v44, %[m0], 0\n\t" \
+        "v_mad_u64_u32 v[54:55], vcc, v58, %[m0], 0\n\t" \
         "v_mad_u64_u32 v[48:49], vcc, v46, %[m1], 0\n\t" \
+        "v_mad_u64_u32 v[62:63], vcc, v60, %[m1], 0\n\t" \
         "v_bitop3_b32 v44, v49, v52, %[k04] bitop3:0x96\n\t" \
+        "v_bitop3_b32 v58, v63, v66, %[k04] bitop3:0x96\n\t" \
         "v_bitop3_b32 v46, v41, v50, %[k14] bitop3:0x96\n\t" \
+        "v_bitop3_b32 v60, v55, v64, %[k14] bitop3:0x96\n\t" \
         "v_mad_u64_u32 v[50:51], vcc, v44, %[m0], 0\n\t" \
+        "v_mad_u64_u32 v[64:65], vcc, v58, %[m0], 0\n\t" \
         "v_mad_u64_u32 v[52:53], vcc, v46, %[m1], 0\n\t" \
+        "v_mad_u64_u32 v[66:67], vcc, v60, %[m1], 0\n\t" \
         "v_bitop3_b32 v44, v53, v48, %[k05] bitop3:0x96\n\t" \
+        "v_bitop3_b32 v58, v67, v62, %[k05] bitop3:0x96\n\t" \
         "v_bitop3_b32 v46, v51, v40, %[k15] bitop3:0x96\n\t" \
+        "v_bitop3_b32 v60, v65, v54, %[k15] bitop3:0x96\n\t" \
         "v_mad_u64_u32 v[40:41], vcc, v44, %[m0], 0\n\t" \
+        "v_mad_u64_u32 v[54:55], vcc, v58, %[m0], 0\n\t" \
         "v_mad_u64_u32 v[48:49], vcc, v46, %[m1], 0\n\t" \
+        "v_mad_u64_u32 v[62:63], vcc, v60, %[m1], 0\n\t" \
         "v_bitop3_b32 v44, v49, v52, %[k06] bitop3:0x96\n\t" \
+        "v_bitop3_b32 v58, v63, v66, %[k06] bitop3:0x96\n\t" \
         "v_bitop3_b32 v46, v41, v50, %[k16] bitop3:0x96\n\t" \
+        "v_bitop3_b32 v60, v55, v64, %[k16] bitop3:0x96\n\t" \
         "v_mad_u64_u32 v[50:51], vcc, v44, %[m0], 0\n\t" \
+        "v_mad_u64_u32 v[64:65], vcc, v58, %[m0], 0\n\t" \
         "v_mad_u64_u32 v[52:53], vcc, v46, %[m1], 0\n\t" \
+        "v_mad_u64_u32 v[66:67], vcc, v60, %[m1], 0\n\t" \
         "v_bitop3_b32 v44, v53, v48, %[k07] bitop3:0x96\n\t" \
+        "v_bitop3_b32 v58, v67, v62, %[k07] bitop3:0x96\n\t" \
         "v_bitop3_b32 v46, v51, v40, %[k17] bitop3:0x96\n\t" \
+        "v_bitop3_b32 v60, v65, v54, %[k17] bitop3:0x96\n\t" \
         "v_mad_u64_u32 v[40:41], vcc, v44, %[m0], 0\n\t" \
+        "v_mad_u64_u32 v[54:55], vcc, v58, %[m0], 0\n\t" \
         "v_mad_u64_u32 v[48:49], vcc, v46, %[m1], 0\n\t" \
+        "v_mad_u64_u32 v[62:63], vcc, v60, %[m1], 0\n\t" \
         "v_bitop3_b32 v44, v49, v52, %[k08] bitop3:0x96\n\t" \
+        "v_bitop3_b32 v58, v63, v66, %[k08] bitop3:0x96\n\t" \
         "v_bitop3_b32 v46, v41, v50, %[k18] bitop3:0x96\n\t" \
+        "v_bitop3_b32 v60, v55, v64, %[k18] bitop3:0x96\n\t" \
         "v_mad_u64_u32 v[50:51], vcc, v44, %[m0], 0\n\t" \
+        "v_mad_u64_u32 v[64:65], vcc, v58, %[m0], 0\n\t" \
         "v_mad_u64_u32 v[52:53], vcc, v46, %[m1], 0\n\t" \
+        "v_mad_u64_u32 v[66:67], vcc, v60, %[m1], 0\n\t" \
         "v_bitop3_b32 v44, v53, v48, %[k09] bitop3:0x96\n\t" \
+        "v_bitop3_b32 v58, v67, v62, %[k09] bitop3:0x96\n\t" \
         "v_bitop3_b32 v46, v51, v40, %[k19] bitop3:0x96\n\t" \
+        "v_bitop3_b32 v60, v65, v54, %[k19] bitop3:0x96\n\t" \
         "v_cmp_lt_u32 vcc, %[t0], v50\n\t" \
         "v_addc_co_u32 %[pk], vcc, 0, 0, vcc\n\t" \
         "v_cmp_lt_u32 vcc, %[t0], v46\n\t" \
@@ -157,57 +196,20 @@ __device__ __forceinline__ RowKeys make_row_keys(uint32_t k0, uint32_t k1)
         "v_addc_co_u32 %[pk], vcc, %[pk], %[pk], vcc\n\t" \
         "v_cmp_lt_u32 vcc, %[t0], v44\n\t" \
         "v_addc_co_u32 %[pk], vcc, %[pk], %[pk], vcc\n\t" \
-        "v_lshl_add_u64 v[40:41], %[P], 0, %[offa]\n\t" \
-        "v_xor_b32 v46, %[x0], v41\n\t" \
-        "v_mad_u64_u32 v[52:53], vcc, v46, %[m1], 0\n\t" \
-        "v_xor_b32 v44, %[x1], v53\n\t" \
-        "v_xor_b32 v46, %[x2], v40\n\t" \
-        "v_mad_u64_u32 v[40:41], vcc, v44, %[m0], 0\n\t" \
-        "v_mad_u64_u32 v[48:49], vcc, v46, %[m1], 0\n\t" \
-        "v_bitop3_b32 v44, v49, v52, %[k02] bitop3:0x96\n\t" \
-        "v_xor_b32 v46, %[x3], v41\n\t" \
-        "v_mad_u64_u32 v[50:51], vcc, v44, %[m0], 0\n\t" \
-        "v_mad_u64_u32 v[52:53], vcc, v46, %[m1], 0\n\t" \
-        "v_bitop3_b32 v44, v53, v48, %[k03] bitop3:0x96\n\t" \
-        "v_bitop3_b32 v46, v51, v40, %[k13] bitop3:0x96\n\t" \
-        "v_mad_u64_u32 v[40:41], vcc, v44, %[m0], 0\n\t" \
-        "v_mad_u64_u32 v[48:49], vcc, v46, %[m1], 0\n\t" \
-        "v_bitop3_b32 v44, v49, v52, %[k04] bitop3:0x96\n\t" \
-        "v_bitop3_b32 v46, v41, v50, %[k14] bitop3:0x96\n\t" \
-        "v_mad_u64_u32 v[50:51], vcc, v44, %[m0], 0\n\t" \
-        "v_mad_u64_u32 v[52:53], vcc, v46, %[m1], 0\n\t" \
-        "v_bitop3_b32 v44, v53, v48, %[k05] bitop3:0x96\n\t" \
-        "v_bitop3_b32 v46, v51, v40, %[k15] bitop3:0x96\n\t" \
-        "v_mad_u64_u32 v[40:41], vcc, v44, %[m0], 0\n\t" \
-        "v_mad_u64_u32 v[48:49], vcc, v46, %[m1], 0\n\t" \
-        "v_bitop3_b32 v44, v49, v52, %[k06] bitop3:0x96\n\t" \
-        "v_bitop3_b32 v46, v41, v50, %[k16] bitop3:0x96\n\t" \
-        "v_mad_u64_u32 v[50:51], vcc, v44, %[m0], 0\n\t" \
-        "v_mad_u64_u32 v[52:53], vcc, v46, %[m1], 0\n\t" \
-        "v_bitop3_b32 v44, v53, v48, %[k07] bitop3:0x96\n\t" \
-        "v_bitop3_b32 v46, v51, v40, %[k17] bitop3:0x96\n\t" \
-        "v_mad_u64_u32 v[40:41], vcc, v44, %[m0], 0\n\t" \
-        "v_mad_u64_u32 v[48:49], vcc, v46, %[m1], 0\n\t" \
-        "v_bitop3_b32 v44, v49, v52, %[k08] bitop3:0x96\n\t" \
-        "v_bitop3_b32 v46, v41, v50, %[k18] bitop3:0x96\n\t" \
-        "v_mad_u64_u32 v[50:51], vcc, v44, %[m0], 0\n\t" \
-        "v_mad_u64_u32 v[52:53], vcc, v46, %[m1], 0\n\t" \
-        "v_bitop3_b32 v44, v53, v48, %[k09] bitop3:0x96\n\t" \
-        "v_bitop3_b32 v46, v51, v40, %[k19] bitop3:0x96\n\t" \
-        "v_cmp_lt_u32 vcc, %[t0], v50\n\t" \
+        "v_cmp_lt_u32 vcc, %[t0], v64\n\t" \
         "v_addc_co_u32 %[pk], vcc, %[pk], %[pk], vcc\n\t" \
-        "v_cmp_lt_u32 vcc, %[t0], v46\n\t" \
+        "v_cmp_lt_u32 vcc, %[t0], v60\n\t" \
         "v_addc_co_u32 %[pk], vcc, %[pk], %[pk], vcc\n\t" \
-        "v_cmp_lt_u32 vcc, %[t0], v52\n\t" \
+        "v_cmp_lt_u32 vcc, %[t0], v66\n\t" \
         "v_addc_co_u32 %[pk], vcc, %[pk], %[pk], vcc\n\t" \
-        "v_cmp_lt_u32 vcc, %[t0], v44\n\t" \
-        "v_addc_co_u32 %[pk], vcc, %[pk], %[pk], vcc\n\t" \
+        "v_cmp_lt_u32 vcc, %[t0], v58\n\t" \
+        "v_addc_co_u32 %[pk], vcc, %[pk], %[pk], vcc\n\t"
 
 #define DNAF_GROUP_KEYS(k) \
     [k02] "s"((k).k02), [k03] "s"((k).k0[0]), [k04] "s"((k).k0[1]), [k05] "s"((k).k0[2]), [k06] "s"((k).k0[3]), [k07] "s"((k).k0[4]), \
     [k08] "s"((k).k0[5]), [k09] "s"((k).k0[6]), [k13] "s"((k).k1[0]), [k14] "s"((k).k1[1]), [k15] "s"((k).k1[2]), [k16] "s"((k).k1[3]), \
     [k17] "s"((k).k1[4]), [k18] "s"((k).k1[5]), [k19] "s"((k).k1[6])
-#define DNAF_GROUP_CLOBBERS "v40", "v41", "v44", "v46", "v48", "v49", "v50", "v51", "v52", "v53", "vcc"
+#define DNAF_GROUP_CLOBBERS "v40", "v41", "v44", "v46", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v58", "v60", "v62", "v63", "v64", "v65", "v66", "v67", "vcc"
 
 __device__ __forceinline__ uint32_t group_code(uint64_t P, uint64_t offa, uint64_t offb, const RowConst& rc, const RowKeys& k, uint32_t t0)
 {
