@@ -7,6 +7,7 @@
 #include "../../include/dnaf.h"
 #include "rowgen_kernels.hip.h"
 #include "rowrun_kernels.hip.h"
+#include "rowmix_kernels.hip.h"
 #include "bgzf_kernels.hip.h"
 #include "gtz_kernels.hip.h"
 #include "bed_kernels.hip.h"
@@ -134,6 +135,8 @@ struct dnaf_ctx {
     bool force_segments = false;     // DNAF_FORCE_SEGMENTS=1: always the segment form of the kernel (A/B runs, tests)
     uint64_t min_run_waves = 8192;   // fewer runs than this and long rows: the segment form fills the GPU better
     uint32_t force_rpw = 0;          // DNAF_ROWS_PER_WAVE: rows per wave of the line-owning form (tests)
+    bool no_rowmix = false;          // DNAF_NO_ROWMIX=1: never the short-row form (A/B runs)
+    uint32_t mix_max_groups = 150;   // rows of fewer groups than this (S < 600) take the short-row form (measured crossover)
     uint32_t run_lds_pad = DNAF_RUN_LDS_PAD_DEFAULT; // unused dynamic LDS per workgroup of rowrun_kernel: caps the workgroups per CU
 };
 
@@ -202,6 +205,8 @@ int dnaf_create(int device, dnaf_ctx** out)
     }
     if (const char* s = getenv("DNAF_FORCE_SEGMENTS")) c->force_segments = atoi(s) != 0;
     if (const char* s = getenv("DNAF_MIN_RUN_WAVES")) c->min_run_waves = strtoull(s, nullptr, 10);
+    if (const char* s = getenv("DNAF_NO_ROWMIX")) c->no_rowmix = atoi(s) != 0;
+    if (const char* s = getenv("DNAF_MIX_MAX_GROUPS")) c->mix_max_groups = (uint32_t)strtoul(s, nullptr, 10);
     if (const char* s = getenv("DNAF_RUN_LDS_PAD")) c->run_lds_pad = (uint32_t)std::min<unsigned long long>(strtoull(s, nullptr, 10), 48u << 10);
     if (const char* s = getenv("DNAF_ROWS_PER_WAVE")) c->force_rpw = (uint32_t)std::min<unsigned long long>(strtoull(s, nullptr, 10), 1u << 20);
     if (const char* s = getenv("DNAF_SEG_ITERS")) {
@@ -732,9 +737,17 @@ int dnaf_generate(dnaf_ctx* c, uint64_t row_begin, uint64_t n_rows, uint32_t wha
         while (rpw > 1 && n_rows / rpw < 16384) rpw /= 2;
         if (c->force_rpw) rpw = c->force_rpw;
     }
-    const bool use_runs = c->G >= 256u && row_bytes_min >= 256 && !c->force_segments && (p.nseg == 1 || n_rows / rpw >= c->min_run_waves);
+    bool use_runs = c->G >= 256u && row_bytes_min >= 256 && !c->force_segments && (p.nseg == 1 || n_rows / rpw >= c->min_run_waves);
+    // short rows (dense packed pitch): the lanes of a trip span rows (rowmix_kernels.hip.h); a wave takes about 2048 groups
+    const bool use_mix = c->S >= 1u && c->Wp == c->W && c->G < c->mix_max_groups && !c->force_segments && !c->no_rowmix;
+    if (use_mix) {
+        use_runs = false;
+        rpw = (uint32_t)std::min<uint64_t>(64, std::max<uint64_t>(1, (2048 + c->G - 1) / c->G));
+        while (rpw > 1 && n_rows / rpw < 16384) rpw /= 2;
+        if (c->force_rpw) rpw = std::min<uint32_t>(c->force_rpw, 64u);
+    }
     p.rows_per_wave = rpw;
-    const uint64_t items = use_runs ? (n_rows + rpw - 1) / rpw : n_rows * p.nseg;
+    const uint64_t items = (use_runs || use_mix) ? (n_rows + rpw - 1) / rpw : n_rows * p.nseg;
     const uint64_t blocks = (items + 3) / 4;
     if (blocks > 0x7FFFFFFFull) return fail(c, DNAF_ERR_UNSUPPORTED, "dnaf_generate: %llu workgroups; generate fewer rows per call", (unsigned long long)blocks);
     // one event pair per launch, on the launch stream (pool bounded: later launches go unrecorded)
@@ -748,8 +761,14 @@ int dnaf_generate(dnaf_ctx* c, uint64_t row_begin, uint64_t n_rows, uint32_t wha
     }
     if (rec) HIP_TRY(c, hipEventRecord(c->evs[2 * c->n_timed], c->stream));
     const dim3 grid((uint32_t)blocks), block(256);
-    if (use_runs) {
-        const uint32_t pad = c->run_lds_pad;
+    if (use_mix) {
+        if (what == (DNAF_OUT_TEXT | DNAF_OUT_PACKED)) hipLaunchKernelGGL((dnaf::rowmix_kernel<true, true>), grid, block, 0, c->stream, p);
+        else if (what == DNAF_OUT_TEXT) hipLaunchKernelGGL((dnaf::rowmix_kernel<true, false>), grid, block, 0, c->stream, p);
+        else hipLaunchKernelGGL((dnaf::rowmix_kernel<false, true>), grid, block, 0, c->stream, p);
+    } else if (use_runs) {
+        // the cap on workgroups per CU pays for long rows (a wave's passes get closer in time); waves that walk several
+        // short rows have more per-row latency to cover and want the full occupancy (S = 4,000: 0.61 without, 0.57 with)
+        const uint32_t pad = rpw <= 2 ? c->run_lds_pad : 0u;
         if (what == (DNAF_OUT_TEXT | DNAF_OUT_PACKED)) hipLaunchKernelGGL((dnaf::rowrun_kernel<true, true>), grid, block, pad, c->stream, p);
         else if (what == DNAF_OUT_TEXT) hipLaunchKernelGGL((dnaf::rowrun_kernel<true, false>), grid, block, pad, c->stream, p);
         else hipLaunchKernelGGL((dnaf::rowrun_kernel<false, true>), grid, block, pad, c->stream, p);
@@ -915,6 +934,17 @@ int dnaf_read_packed(dnaf_ctx* c, uint32_t* dst, uint64_t dst_cap_words, uint64_
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return DNAF_OK;
 }
+
+#ifdef DNAF_GTZ_PROFILE
+// debug builds: read and reset the stage clock of gtz_encode (tools/gtz_stage_profile.py)
+int dnaf_debug_gtz_profile(unsigned long long* out16)
+{
+    unsigned long long z[16] = {0};
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(dnaf::gtz_prof), sizeof z) != hipSuccess) return DNAF_ERR_HIP;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(dnaf::gtz_prof), z, sizeof z) != hipSuccess) return DNAF_ERR_HIP;
+    return DNAF_OK;
+}
+#endif
 
 int dnaf_packed_pitch_words(const dnaf_ctx* c, uint64_t* pitch_words)
 {

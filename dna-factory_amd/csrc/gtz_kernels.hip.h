@@ -275,9 +275,20 @@ __device__ __forceinline__ uint32_t gtz_text_byte(const GtzParams& p, const GtzS
     return '0' + (which == 0u ? (code & 1u) : (code >> 1));
 }
 
+#ifdef DNAF_GTZ_PROFILE
+// stage clock of gtz_encode<false>: cycles (s_memtime) summed over workgroups, per stage; debug builds only
+__device__ unsigned long long gtz_prof[16];
+#define GTZ_STAMP(k) do { if (!HIST && tid == 0) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); atomicAdd(&gtz_prof[k], t_ - t_prev_); t_prev_ = t_; } } while (0)
+#else
+#define GTZ_STAMP(k) do { } while (0)
+#endif
+
 template <bool HIST>
 __global__ __launch_bounds__(GTZ_THREADS) void gtz_encode(const GtzParams p)
 {
+#ifdef DNAF_GTZ_PROFILE
+    unsigned long long t_prev_ = __builtin_amdgcn_s_memtime();
+#endif
     __shared__ GtzShared sh;
     GtzShared* s = &sh;
     const uint32_t tid = threadIdx.x;
@@ -357,6 +368,7 @@ __global__ __launch_bounds__(GTZ_THREADS) void gtz_encode(const GtzParams p)
     }
     const uint32_t nr = s->nr, n_items = s->n_items, klass = s->klass;
     const GtzClassTables* ct = &p.tables->cls[klass];
+    GTZ_STAMP(0); // rows located, layout decided
 
     // ---- g space, key tables, code tables ----
     for (uint32_t i = 0; i < nr; ++i) {
@@ -379,6 +391,7 @@ __global__ __launch_bounds__(GTZ_THREADS) void gtz_encode(const GtzParams p)
         if (tid < GTZ_CHUNK_CELLS) { s->crc_unit_a[tid] = p.tables->crc_unit_a[tid]; s->crc_unit_b[tid] = p.tables->crc_unit_b[tid]; }
     }
     __syncthreads();
+    GTZ_STAMP(1); // cells and code tables in LDS
     // Key tables, one quarter of the g space at a time: earliest / latest position of every key with 32-bit LDS
     // atomics in a scratch area (the match lists' space, not yet in use), then narrowed to 16 bits -- the tables
     // that stay are 16 KB instead of 32, which is what lets a fourth workgroup share the CU.
@@ -414,6 +427,7 @@ __global__ __launch_bounds__(GTZ_THREADS) void gtz_encode(const GtzParams p)
         }
     }
 
+    GTZ_STAMP(2); // key tables
     // code lengths of the four literals a cell is made of, one byte each
     const uint32_t lit_bits = HIST ? 0u : (s->lit()['0'] & 31u) | ((s->lit()['1'] & 31u) << 8) | ((s->lit()['/'] & 31u) << 16) | ((s->lit()['\t'] & 31u) << 24);
     // ---- pass 1: search, then tokenise to count bits (or symbols); CRC ----
@@ -499,6 +513,7 @@ __global__ __launch_bounds__(GTZ_THREADS) void gtz_encode(const GtzParams p)
     }
 
     // ---- offsets: exclusive scan of the items' bit counts (items tid, then items 256 + tid) ----
+    GTZ_STAMP(3); // thread 0's own search + tokens + count + CRC (not the slowest thread's)
     const uint32_t lane = tid & 63u, wave = tid >> 6;
     uint32_t incl0 = bits[0], incl1 = bits[1];
 #pragma unroll
@@ -511,6 +526,7 @@ __global__ __launch_bounds__(GTZ_THREADS) void gtz_encode(const GtzParams p)
     if (lane == 63u) { s->scratch[wave] = incl0; s->scratch[GTZ_WAVES + wave] = incl1; }
     if (lane == 0u) s->scratch[2 * GTZ_WAVES + wave] = part;
     __syncthreads(); // also: every search is done, the key tables are free
+    GTZ_STAMP(4); // waiting for the slowest thread's pass 1
     uint32_t base0 = 0, base1 = 0, tot0 = 0, tot1 = 0, member_crc = 0;
     for (uint32_t w = 0; w < GTZ_WAVES; ++w) {
         const uint32_t a = s->scratch[w], b = s->scratch[GTZ_WAVES + w];
@@ -529,6 +545,7 @@ __global__ __launch_bounds__(GTZ_THREADS) void gtz_encode(const GtzParams p)
         return;
     }
 
+    GTZ_STAMP(5);
     // ---- pass 2: the member image in LDS ----
     const uint32_t image_words = (size + 3u) >> 2;
     for (uint32_t t = tid; t < image_words; t += GTZ_THREADS) s->image[t] = 0;
@@ -572,10 +589,13 @@ __global__ __launch_bounds__(GTZ_THREADS) void gtz_encode(const GtzParams p)
         p.sizes[m] = size;
         p.fast[m] = 1;
     }
+    GTZ_STAMP(6); // thread 0's emission
     __syncthreads();
+    GTZ_STAMP(7); // waiting for the slowest thread's emission
     uint4* dst = reinterpret_cast<uint4*>(p.stage + (uint64_t)m * GTZ_STRIDE);
     const uint4* src = reinterpret_cast<const uint4*>(s->image);
     for (uint32_t t = tid; t < (size + 15u) >> 4; t += GTZ_THREADS) dst[t] = src[t];
+    GTZ_STAMP(8); // copy to the staging slot
 }
 
 // staging slot -> the member's place in the stream (offsets from bgzf_scan)

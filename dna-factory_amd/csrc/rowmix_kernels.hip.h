@@ -1,0 +1,215 @@
+// rowmix_kernels.hip.h -- the row generator for SHORT rows (gfx950 / CDNA4): the lanes of a trip span rows.
+//
+// rowgen_kernel / rowrun_kernel give a trip's 64 lanes to 64 consecutive groups of ONE row.  A row of a few
+// hundred samples has fewer groups than that (S = 200: 50), so most of the work would be the per-row fixed part --
+// a partly filled trip, the row's scalar set-up, its fixed columns (0.13 of the HBM peak at S = 100, 0.21 at 200).
+// Here a wave owns a run of up to 64 whole rows and treats the groups of consecutive ordinary rows (biallelic
+// autosome, no forced cells: almost every row) as ONE sequence q = 0, 1, 2, ...: lane l of trip t takes
+// q = 64 t + l, i.e. row q / G, group q mod G.  What differs between rows -- the four folded Philox constants, the
+// threshold, where the row's cells start -- is computed once per row by one lane each and kept in a small LDS table;
+// the Philox group sequence runs with these in vector registers (group_code_lanes, rowrun_kernels.hip.h).  The fixed
+// columns of a row are copied during the trip in which the row begins, so that they reach the L2 next to the cells
+// around them.  Any other row of the run (X / Y / MT, multi-allelic, forced cells) is written by the row-at-a-time
+// code of rowrun_kernels.hip.h in between.
+//
+// Same cell rules, RNG lane mapping and text format as everywhere (pop_factory.py:471-513, rowgen_kernels.hip.h).
+// Used for rows of fewer than 150 groups (S < 600): 0.23 instead of 0.13 of the HBM peak at S = 100, 0.30 / 0.21 at 200,
+// 0.33 / 0.30 at 400; from 600 samples on a wave per row segment is as fast (profiles/r02_shapes.txt).  The kernel is bound
+// by its instruction count here too: the per-lane bookkeeping (row and group of a lane, addresses, the fixed columns)
+// is 50 instructions on top of the 90 of the Philox group.
+#pragma once
+#include "rowrun_kernels.hip.h"
+
+namespace dnaf {
+
+struct MixRow {        // what a lane needs of its row, 32 bytes in LDS
+    uint32_t x0, x1, x2, x3;
+    uint32_t t0, cells_rel, pad0, pad1; // cells_rel: the row's first cell byte, relative to the run's first text byte
+};
+
+// q / d and q mod d for q < 2^22, d < 2^16 with m = floor(2^32 / d): one multiply-high, one correction step
+__device__ __forceinline__ void divmod_small(uint32_t q, uint32_t d, uint32_t m, uint32_t& quot, uint32_t& rem)
+{
+    uint32_t r = __umulhi(q, m);
+    uint32_t g = q - r * d;
+    if (g >= d) { g -= d; ++r; }
+    quot = r;
+    rem = g;
+}
+
+constexpr uint32_t MIX_PFX_BYTES = 3072; // the fixed columns of a run's rows, cached in LDS (64 rows x 48 bytes)
+
+template <bool TEXT, bool PACKED>
+__global__ __launch_bounds__(256) void rowmix_kernel(const GenParams p)
+{
+    __shared__ u32x4_t cell_lut[256];
+    __shared__ __attribute__((aligned(16))) uint8_t pk_stage[4][PK_STAGE];
+    __shared__ __attribute__((aligned(16))) MixRow rows_all[4][64];
+    __shared__ __attribute__((aligned(16))) uint8_t pfx_all[4][MIX_PFX_BYTES];
+    if (TEXT) {
+        const uint32_t t = threadIdx.x;
+        const u32x4_t e = {CELL00 + (t & 1u) + ((t & 2u) << 15), CELL00 + ((t >> 2) & 1u) + ((t & 8u) << 13),
+                           CELL00 + ((t >> 4) & 1u) + ((t & 32u) << 11), CELL00 + ((t >> 6) & 1u) + ((t & 128u) << 9)};
+        cell_lut[t] = e;
+        __syncthreads();
+    }
+    const uint32_t lane_id = threadIdx.x & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint64_t run = (uint64_t)blockIdx.x * 4u + wave;
+    const uint32_t R = p.rows_per_wave; // <= 64
+    const uint64_t j0 = run * R;
+    if (j0 >= p.n_rows) return;
+    const uint32_t nrun = (uint32_t)min((uint64_t)R, p.n_rows - j0);
+    const uint32_t G = p.G, S = p.S;
+    const uint32_t g_stop = PACKED ? p.W * 4u : G;
+    LDS_PTR(MixRow) tab = (LDS_PTR(MixRow))rows_all[threadIdx.x >> 6];
+
+    SegCtx c;
+    c.lut = (const LDS_PTR(u32x4_t))cell_lut;
+    c.stage = (LDS_PTR(uint8_t))pk_stage[threadIdx.x >> 6];
+
+    // one lane per row of the run: its record, whether it is an ordinary row, its constants -> LDS
+    const uint64_t text0 = p.recs[p.row_begin + j0].text_off; // first text byte of the run
+    uint8_t* run_text = p.text + (text0 - p.text_base);
+    uint8_t* packed_run = p.packed + j0 * p.packed_pitch;
+    const uint32_t pitch32 = (uint32_t)p.packed_pitch;
+    RowRec myrec = p.recs[p.row_begin + j0 + (lane_id < nrun ? lane_id : 0u)];
+    const bool ordinary = lane_id < nrun && myrec.cls == 0u && myrec.n_alleles == 2 && myrec.slot < 0;
+    const uint32_t my_rel = (uint32_t)(myrec.text_off - text0), my_plen = myrec.prefix_len, my_poff = myrec.prefix_off;
+    {
+        SegCtx cr;
+        const uint64_t rng_row = p.rng_row0 + p.row_begin + j0 + lane_id;
+        cr.r_lo = (uint32_t)rng_row; cr.r_hi = (uint32_t)(rng_row >> 32);
+        cr.k0 = p.key0; cr.k1 = p.key1;
+        const RowConst rc = make_row_const(cr);
+        MixRow e;
+        e.x0 = rc.x0; e.x1 = rc.x1; e.x2 = rc.x2; e.x3 = rc.x3;
+        e.t0 = myrec.thr[0]; e.cells_rel = my_rel + myrec.prefix_len; e.pad0 = e.pad1 = 0;
+        if (lane_id < nrun) {
+            *reinterpret_cast<LDS_PTR(u32x4_t)>(&tab[lane_id]) = u32x4_t{e.x0, e.x1, e.x2, e.x3};
+            *reinterpret_cast<LDS_PTR(u32x4_t)>(&tab[lane_id].t0) = u32x4_t{e.t0, e.cells_rel, 0u, 0u};
+        }
+    }
+    const uint64_t ord_mask = __ballot(ordinary);
+    // The fixed columns of the run's rows are one contiguous piece of the prefix blob: into LDS with one round of loads, so
+    // that no trip waits on a global load for the few dozen bytes in front of a row (that wait, once per row, was what
+    // bound the kernel at 200 samples).
+    const uint32_t pfx0 = __builtin_amdgcn_readlane(my_poff, 0);
+    const uint32_t pfx_bytes = __builtin_amdgcn_readlane(my_poff + my_plen, nrun - 1u) - pfx0;
+    const bool pfx_cached = TEXT && pfx_bytes <= MIX_PFX_BYTES;
+    LDS_PTR(uint8_t) pfx = (LDS_PTR(uint8_t))pfx_all[threadIdx.x >> 6];
+    if (pfx_cached)
+        for (uint32_t i = lane_id; i < pfx_bytes; i += 64u) pfx[i] = p.prefix[pfx0 + i];
+    const RowKeys keys = make_row_keys(p.key0, p.key1);
+    const uint32_t gmagic = (uint32_t)min(0x100000000ull / G, 0xFFFFFFFFull);
+    const uint32_t nvalid_last = S - 4u * (G - 1u); // samples in a row's last group, 1 .. 4
+    const uint32_t fix = 0x0A000000u - 0x09000000u; // '\n' instead of the last '\t'
+
+    uint32_t r = 0;
+    while (r < nrun) {
+        uint32_t lane = lane_id; // an opaque copy per stretch: keeps lane-derived values out of registers across the loop
+        asm volatile("" : "+v"(lane));
+        if (!((ord_mask >> r) & 1ull)) {
+            // any other kind of row: a row at a time (rowrun_kernels.hip.h), whole, with this wave's own first and last bytes
+            const RowRec rec = p.recs[p.row_begin + j0 + r];
+            uint8_t* row_text = p.text + (rec.text_off - p.text_base);
+            if (TEXT) {
+                const uint8_t* src = p.prefix + rec.prefix_off;
+                for (uint32_t i = lane; i < rec.prefix_len; i += 64) row_text[i] = src[i];
+            }
+            make_ctx(c, p, rec, j0 + r, row_text);
+            const HeadJob none{};
+            if (rec.n_alleles > 2) run_row_other<TEXT, PACKED, true>(c, rec.cls, 0u, g_stop, lane);
+            else if (rec.cls != 0u) run_row_other<TEXT, PACKED, false>(c, rec.cls, 0u, g_stop, lane);
+            else (void)run_row_biallelic<TEXT, PACKED, false>(c, 0u, g_stop, none, lane); // forced cells
+            ++r;
+            continue;
+        }
+        // the stretch of ordinary rows [r, e)
+        const uint64_t rest = ~(ord_mask >> r);
+        const uint32_t len = rest ? (uint32_t)__builtin_ctzll(rest) : 64u;
+        const uint32_t e = min(nrun, r + len);
+        const uint32_t n = (e - r) * G; // groups of the stretch
+        uint32_t next_row = r, next_q = 0; // the next row whose first group has not been reached yet
+        // Software pipeline over the trips: the row-table entries of trip t+1 are read before trip t's arithmetic, and the
+        // text of trip t (a look-up in the LDS cell table) is stored after trip t+1's arithmetic -- no trip waits on LDS.
+        auto coords = [&](uint32_t qb, uint32_t& row, uint32_t& g, bool& live) {
+            const uint32_t q = qb + lane;
+            live = q < n;
+            divmod_small(live ? q : 0u, G, gmagic, row, g);
+            row += r;
+        };
+        uint32_t row0, g0;
+        bool live0;
+        coords(0u, row0, g0, live0);
+        u32x4_t xs0 = *reinterpret_cast<const LDS_PTR(u32x4_t)>(&tab[row0]);
+        u32x4_t ts0 = *reinterpret_cast<const LDS_PTR(u32x4_t)>(&tab[row0].t0);
+        bool have_prev = false, live_prev = false, last_prev = false;
+        u32x4_t w_prev = {0, 0, 0, 0};
+        uint32_t off_prev = 0;
+        auto store_prev = [&]() {
+            if (!live_prev) return;
+            uint8_t* dst = run_text + off_prev;
+            if (nvalid_last == 4u) { // wave-uniform: every group is whole, the row's last one ends in a newline
+                w_prev.w += last_prev ? fix : 0u;
+                store_unaligned<16>(dst, &w_prev);
+            } else if (!last_prev) store_unaligned<16>(dst, &w_prev);
+            else { // the group with the row's last sample: newline instead of the last tab, fewer than 4 samples
+                const uint32_t w0 = w_prev.x + (nvalid_last == 1u ? fix : 0u), w1 = w_prev.y + (nvalid_last == 2u ? fix : 0u);
+                const uint32_t w2 = w_prev.z + (nvalid_last == 3u ? fix : 0u);
+                store_unaligned<4>(dst, &w0);
+                if (nvalid_last > 1u) store_unaligned<4>(dst + 4, &w1);
+                if (nvalid_last > 2u) store_unaligned<4>(dst + 8, &w2);
+            }
+        };
+        for (uint32_t qb = 0; qb < n; qb += 64u) {
+            uint32_t row1 = row0, g1 = g0;
+            bool live1 = false;
+            u32x4_t xs1 = xs0, ts1 = ts0;
+            if (qb + 64u < n) { // wave-uniform
+                coords(qb + 64u, row1, g1, live1);
+                xs1 = *reinterpret_cast<const LDS_PTR(u32x4_t)>(&tab[row1]);
+                ts1 = *reinterpret_cast<const LDS_PTR(u32x4_t)>(&tab[row1].t0);
+            }
+            if (TEXT) {
+                // fixed columns of the rows that begin in this trip (pop_factory.py:503-507, formatted on the host)
+                while (next_row < e && next_q < qb + 64u) {
+                    const uint32_t plen = __builtin_amdgcn_readlane(my_plen, next_row);
+                    const uint32_t poff = __builtin_amdgcn_readlane(my_poff, next_row);
+                    const uint32_t rel = __builtin_amdgcn_readlane(my_rel, next_row);
+                    if (pfx_cached) { for (uint32_t i = lane; i < plen; i += 64) run_text[rel + i] = pfx[poff - pfx0 + i]; }
+                    else { for (uint32_t i = lane; i < plen; i += 64) run_text[rel + i] = p.prefix[poff + i]; }
+                    ++next_row;
+                    next_q += G;
+                }
+            }
+            const uint64_t P = (uint64_t)PHILOX_M0 * (2u * g0);
+            uint32_t pk = group_code_lanes(P, xs0.x, xs0.y, xs0.z, xs0.w, ts0.x, keys);
+            const bool last = g0 == G - 1u;
+            if (TEXT) {
+                if (have_prev) store_prev();
+                w_prev = c.lut[pk & 0xFFu];
+                off_prev = ts0.y + 16u * g0;
+                live_prev = live0;
+                last_prev = last;
+                have_prev = true;
+            }
+            if (PACKED && live0) {
+                if (last) pk &= (1u << (2u * nvalid_last)) - 1u; // codes of samples past the end stay 0
+                packed_run[row0 * pitch32 + g0] = (uint8_t)pk;   // 32-bit offsets from the run's first packed byte
+            }
+            row0 = row1; g0 = g1; live0 = live1; xs0 = xs1; ts0 = ts1;
+        }
+        if (TEXT && have_prev) store_prev();
+        if (PACKED && g_stop > G) { // pad bytes of the stretch's packed rows (at most 3 per row)
+            const uint32_t npad = g_stop - G;
+            for (uint32_t i = lane; i < (e - r) * npad; i += 64u) {
+                const uint32_t rr = i / npad, k = i - rr * npad;
+                packed_run[(r + rr) * pitch32 + G + k] = 0;
+            }
+        }
+        r = e;
+    }
+}
+
+} // namespace dnaf

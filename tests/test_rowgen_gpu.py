@@ -302,6 +302,39 @@ def test_line_owning_kernel_fuzz(RowGenerator, oracle, monkeypatch, rpw):
         check_case(RowGenerator, oracle, snps, samples, seed=int(rs.randint(0, 2**31)), rng_row0=int(rs.randint(0, 1000)))
 
 
+@pytest.mark.parametrize("rpw", [1, 5, 64])
+def test_short_row_kernel_fuzz(RowGenerator, oracle, monkeypatch, rpw):
+    """The short-row form (rowmix_kernels.hip.h: the lanes of a trip span the rows of a wave's run) at 1 .. 64 rows per
+    wave: sample counts from 1 to 2,032 (one group per row, rows shorter and longer than a trip, last groups of 1-4
+    samples, pad bytes in the packed rows), stretches of ordinary rows broken by X / Y / MT, multi-allelic and forced
+    rows."""
+    monkeypatch.setenv("DNAF_ROWS_PER_WAVE", str(rpw))
+    rs = np.random.RandomState(4000 + rpw)
+    pools = [range(1, 9), range(9, 70), range(190, 270), range(500, 530), range(1000, 1030), range(2017, 2033)]
+    for case in range(24):
+        S = int(rs.choice(list(pools[case % len(pools)])))
+        n_rows = int(rs.randint(1, 200 if S < 300 else 90))
+        snps, samples = random_case(rs, n_rows, S, p_sex_chrom=0.15 if case % 2 else 0.4, n_del=3 if case % 3 else 0)
+        check_case(RowGenerator, oracle, snps, samples, seed=int(rs.randint(0, 2**31)), rng_row0=int(rs.randint(0, 1000)))
+
+
+def test_short_row_and_segment_forms_write_the_same_bytes(RowGenerator, oracle, monkeypatch):
+    rs = np.random.RandomState(6060)
+    snps, samples = random_case(rs, 700, 200, p_sex_chrom=0.2)
+    outs = []
+    for no_mix in ("1", "0"):
+        monkeypatch.setenv("DNAF_NO_ROWMIX", no_mix)
+        monkeypatch.setenv("DNAF_ROWS_PER_WAVE", "41")
+        with RowGenerator(device=0, seed=21) as g:
+            g.set_samples(samples)
+            g.set_snps(snps)
+            t, off, p = g.generate()
+            outs.append((t.tobytes(), off.tobytes(), p.tobytes()))
+    assert outs[0] == outs[1]
+    want_text, _, want_packed = oracle_run(oracle, snps, samples, 21)
+    assert outs[0][0] == want_text and outs[0][2] == want_packed.tobytes()
+
+
 def test_both_kernel_forms_write_the_same_bytes(RowGenerator, oracle, monkeypatch):
     """DNAF_FORCE_SEGMENTS=1 (a wave per row segment) and the default line-owning form on one mid-size table."""
     rs = np.random.RandomState(5150)
