@@ -35,7 +35,7 @@ SYMBOLS = [
     "dnaf_format_prefixes", "dnaf_bgzf_compress", "dnaf_read_bgzf", "dnaf_last_bgzf_ms",
     "dnaf_bgzf_tables_from_histogram", "dnaf_gtz_tables_from_histogram", "dnaf_set_mt_state", "dnaf_mt_jump_host", "dnaf_mt_characteristic_polynomial",
     "dnaf_fetch_bgzf", "dnaf_fetch_text", "dnaf_read_text_range", "dnaf_format_snps_json", "dnaf_parse_snps_json",
-    "dnaf_allele_counts", "dnaf_export_bed", "dnaf_read_bed", "dnaf_packed_pitch_words",
+    "dnaf_allele_counts", "dnaf_export_bed", "dnaf_read_bed", "dnaf_packed_pitch_words", "dnaf_numpy_legacy_choice",
 ]
 
 
@@ -97,6 +97,7 @@ def _load():
         "dnaf_read_packed": (ci, [vp, vp, u64, vp]),
         "dnaf_device_buffers": (ci, [vp, vp, vp, vp, vp]),
         "dnaf_packed_pitch_words": (ci, [vp, vp]),
+        "dnaf_numpy_legacy_choice": (ci, [vp, vp, u64, u32, vp]),
         "dnaf_format_prefixes": (ci, [u64, vp, u32, vp, vp, vp, u32, vp, u32, vp, u64, vp]),
         "dnaf_bgzf_compress": (ci, [vp, u32, vp]),
         "dnaf_read_bgzf": (ci, [vp, vp, u64, vp]),
@@ -136,6 +137,24 @@ def device_count():
     if rc != OK:
         raise DnafError(rc, lib.dnaf_last_error(None).decode())
     return n.value
+
+
+def numpy_legacy_choice(pop_size, size):
+    """numpy.random.choice(pop_size, size, replace=False) on numpy's global legacy generator -- the same indices, the same
+    generator state afterwards -- without the O(pop_size) shuffle of an array (dnaf_numpy_legacy_choice)."""
+    import numpy
+
+    st = numpy.random.get_state()
+    if st[0] != "MT19937" or size > pop_size or pop_size >= 2**32 or pop_size == 0:
+        return numpy.random.choice(pop_size, size, replace=False)
+    key = np.ascontiguousarray(st[1], dtype=np.uint32).copy()
+    pos = ctypes.c_uint32(int(st[2]))
+    out = np.empty(size, dtype=np.uint64)
+    rc = lib.dnaf_numpy_legacy_choice(ptr(key), ctypes.byref(pos), ctypes.c_uint64(pop_size), ctypes.c_uint32(size), ptr(out))
+    if rc != OK:
+        raise DnafError(rc, "dnaf_numpy_legacy_choice")
+    numpy.random.set_state((st[0], key, int(pos.value), st[3], st[4]))
+    return out.astype(np.int64)
 
 
 def format_prefixes(chrom, pos, snp_id, ref, alt):

@@ -1302,6 +1302,73 @@ int dnaf_mt_jump_host(const uint32_t* base, uint64_t J, uint32_t* window)
     return DNAF_OK;
 }
 
+// numpy.random.choice(pop_size, size, replace=False) of the legacy RandomState (the reference's deleterious picks,
+// pop_factory.py:576): permutation(pop_size)[:size], i.e. numpy's Fisher-Yates shuffle of arange(pop_size) -- for i =
+// pop_size-1 .. 1: j = random_interval(i) (32-bit draws, masked rejection), swap(x[i], x[j]) -- of which only the first
+// `size` entries are wanted.  The draws are replayed exactly (the generator state key[624] / *pos moves on as numpy's
+// would), but nothing is shuffled: the j's are kept and each wanted position is traced back through the swaps in reverse
+// order, one sequential pass.  2 s -> 0.25 s per pick at 40 M SNPs (BASELINE config 4 picks 14 times).
+int dnaf_numpy_legacy_choice(uint32_t* key, uint32_t* pos, uint64_t pop_size, uint32_t size, uint64_t* out_idx)
+{
+    if (!key || !pos || *pos > 624u || (size && !out_idx)) return DNAF_ERR_BAD_ARG;
+    if (size > pop_size || pop_size > 0xFFFFFFFFull) return DNAF_ERR_UNSUPPORTED; // numpy raises / would use 64-bit draws
+    if (pop_size == 0) return DNAF_OK;
+    std::vector<uint32_t> js;
+    try {
+        js.resize((size_t)pop_size);
+    } catch (const std::bad_alloc&) {
+        return DNAF_ERR_OOM;
+    }
+    // tempered outputs a block of 624 at a time (plain loops the compiler vectorises), consumed in order
+    uint32_t p = *pos;
+    uint32_t out[624];
+    auto temper_block = [&]() {
+        for (int i = 0; i < 624; ++i) {
+            uint32_t y = key[i];
+            y ^= y >> 11;
+            y ^= (y << 7) & 0x9D2C5680u;
+            y ^= (y << 15) & 0xEFC60000u;
+            y ^= y >> 18;
+            out[i] = y;
+        }
+    };
+    auto twist = [&]() {
+        auto mix = [](uint32_t a, uint32_t b, uint32_t c) { const uint32_t y = (a & 0x80000000u) | (b & 0x7fffffffu); return c ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u); };
+        int i = 0;
+        for (; i < 624 - 397; ++i) key[i] = mix(key[i], key[i + 1], key[i + 397]);
+        for (; i < 623; ++i) key[i] = mix(key[i], key[i + 1], key[i + 397 - 624]);
+        key[623] = mix(key[623], key[0], key[396]);
+    };
+    if (p < 624u) temper_block();
+    uint32_t mask = (uint32_t)(pop_size - 1); // smallest 2^k - 1 >= i, kept as i falls
+    mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16;
+    for (uint64_t i = pop_size - 1; i >= 1; --i) {
+        if ((uint32_t)i <= (mask >> 1)) mask >>= 1;
+        uint32_t v;
+        do {
+            if (p >= 624u) { twist(); temper_block(); p = 0; }
+            v = out[p++] & mask;
+        } while (v > (uint32_t)i);
+        js[(size_t)i] = v;
+    }
+    *pos = p;
+    // x_final[t] for t < size: undo the swaps from the last executed (i = 1) to the first (i = pop_size-1)
+    for (uint32_t t = 0; t < size; ++t) out_idx[t] = t;
+    // (a swap (i, j) matters only if a traced position is i or j; i is rarely one -- positions start below `size` and move up
+    // only through such swaps -- so the test is a handful of compares per swap)
+    for (uint64_t i = 1; i < pop_size; ++i) {
+        const uint64_t j = js[(size_t)i];
+        bool hit = false;
+        for (uint32_t t = 0; t < size; ++t) hit |= (out_idx[t] == i) | (out_idx[t] == j);
+        if (!hit) continue;
+        for (uint32_t t = 0; t < size; ++t) {
+            const uint64_t at = out_idx[t];
+            out_idx[t] = at == i ? j : (at == j ? i : at);
+        }
+    }
+    return DNAF_OK;
+}
+
 // degree and coefficient words (312 x u64) of the characteristic polynomial (tests)
 int dnaf_mt_characteristic_polynomial(uint64_t* words312, int* degree)
 {

@@ -95,17 +95,62 @@ def generate_snp_table(size, min_maf=0.005):
     position = (position_randoms * max_pos[chrom_idx]).astype(np.int64)  # int(rand * max), pop_factory.py:186
     names = np.array([c.encode() for c in genome.CHROMOSOME_LIST], dtype="S2")
     nt = np.array([c.encode() for c in genome.NUCLEOTIDES], dtype="S1")
-    cum = np.ones((size, 4), dtype=np.float64)
+    # ordered_snps.sort(key=(chromosome, position)), pop_factory.py:245 -- done on the compact columns (one byte of
+    # chromosome rank, the positions), and the table is then built in its final order: at 40 M SNPs the string sort and the
+    # re-ordering of a finished table were half of the front end's time
+    order = _sort_order(_string_rank(names)[chrom_idx], position)
+    chrom_idx, position, ref_idx, alt_idx, mafs = chrom_idx[order], position[order], ref_idx[order], alt_idx[order], mafs[order]
+    cum = np.empty((size, 4), dtype=np.float64)
     cum[:, 0] = 1 - mafs
-    ids = np.arange(1, size + 1, dtype=np.int64)
-    tb = SnpTable(ids, names[chrom_idx], position, nt[ref_idx], nt[alt_idx], np.full(size, 2, np.uint8), cum)
-    return sort_snp_table(tb)
+    cum[:, 1:] = 1.0
+    ids = order.astype(np.int64) + 1  # rs ids are assigned before the sort
+    return SnpTable(ids, names[chrom_idx], position, nt[ref_idx], nt[alt_idx], np.full(size, 2, np.uint8), cum)
+
+
+def _string_rank(names):
+    """rank[i] = position of names[i] in the sorted list of the distinct names (bytewise = Python str order for ASCII)."""
+    uniq, inv = np.unique(names, return_inverse=True)
+    return inv.astype(np.uint8 if len(uniq) <= 256 else np.int64)
+
+
+def _sort_order(rank, position):
+    """Stable order by (rank, position) = list.sort(key=(chromosome, position)): a radix pass over the one-byte ranks,
+    then the positions of every chromosome on their own (numpy's sorts release the GIL: one thread per chromosome)."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    if rank.dtype != np.uint8 or len(rank) < 200000:
+        return np.lexsort((position, rank))
+    by_rank = np.argsort(rank, kind="stable")  # radix sort for 8-bit keys: rows grouped by chromosome, original order inside
+    counts = np.bincount(rank, minlength=256)
+    bounds = np.concatenate([[0], np.cumsum(counts)])
+    out = np.empty(len(rank), dtype=np.int64)
+
+    def one(c):
+        lo, hi = int(bounds[c]), int(bounds[c + 1])
+        if hi > lo:
+            idx = by_rank[lo:hi]
+            out[lo:hi] = idx[np.argsort(position[idx], kind="stable")]
+
+    with ThreadPoolExecutor(max_workers=min(16, os.cpu_count() or 4)) as ex:
+        list(ex.map(one, [c for c in range(256) if counts[c]]))
+    return out
 
 
 def sort_snp_table(tb):
     """ordered_snps.sort(key=(chromosome, position)) -- chromosome compares as a *string* (SURVEY Q9); stable."""
+    if len(tb) > 1:  # already in order (a table from generate_snp_table, or a snps.json.gz the reference wrote): nothing to move
+        w = tb.chrom.dtype.itemsize
+        key = tb.chrom.view(np.uint8).reshape(len(tb), w)
+        same = (key[1:] == key[:-1]).all(axis=1)
+        less = np.zeros(len(tb) - 1, dtype=bool)
+        undecided = np.ones(len(tb) - 1, dtype=bool)
+        for k in range(w):  # bytewise string comparison, most significant byte first
+            less |= undecided & (key[:-1, k] < key[1:, k])
+            undecided &= key[:-1, k] == key[1:, k]
+        if bool(np.all(less | (same & (tb.position[:-1] <= tb.position[1:])))):
+            return tb
     uniq, inv = np.unique(tb.chrom, return_inverse=True)  # uniq is sorted bytewise = Python str order for ASCII
-    order = np.lexsort((tb.position, inv))
+    order = _sort_order(inv.astype(np.uint8) if len(uniq) <= 256 else inv, tb.position)
     return tb.take(order)
 
 
@@ -244,6 +289,8 @@ def pick_deleterious(tb, config_path):
     pop_factory.py:521-538, :560-608).  One numpy.random.choice(ids, k, replace=False) per group instance."""
     import yaml
 
+    from . import capi
+
     with open(config_path, "r") as f:
         cfg = yaml.safe_load(f)
     groups = {}
@@ -264,7 +311,9 @@ def pick_deleterious(tb, config_path):
             g = DeleteriousGroup("%s-%s" % (name, i), attr["population_weight"])
             if len(ids) == 0:
                 raise Exception("No SNPs in list to choose from. SNPs must have all been filtered out by deleterious config.")
-            for w, sid in zip(weights, numpy.random.choice(a=ids, size=len(weights), replace=False)):
+            # numpy.random.choice(a=ids, size=k, replace=False) = ids[permutation(len(ids))[:k]] on the legacy generator
+            # (pop_factory.py:576); the library replays its draws without shuffling 40 M ids fourteen times
+            for w, sid in zip(weights, ids[capi.numpy_legacy_choice(len(ids), len(weights))]):
                 g.deleterious[int(sid)] = w
             groups[g.name] = g
     return groups

@@ -207,6 +207,12 @@ int dnaf_parse_snps_json(const char* text, uint64_t n_bytes, uint64_t max_rows, 
 /* Host-only helpers of the MT19937 mode (tests): the window of 624 untempered words J >= 1 words after
  * base[624]; the characteristic polynomial of the generator (312 coefficient words, degree). */
 int dnaf_mt_jump_host(const uint32_t* base, uint64_t J, uint32_t* window);
+/* Host helper of the seed-compatible front end: numpy.random.choice(pop_size, size, replace=False) of numpy's legacy
+ * RandomState, as the reference's deleterious picks call it (pop_factory.py:576).  key[624] / *pos are
+ * numpy.random.get_state()[1] / [2] and are advanced exactly as numpy would advance them; out_idx[size] receives
+ * permutation(pop_size)[:size].  Replays the draws of numpy's shuffle without shuffling (the wanted entries are traced back
+ * through the swaps).  DNAF_ERR_UNSUPPORTED: size > pop_size or pop_size >= 2^32 (let numpy handle / raise). */
+int dnaf_numpy_legacy_choice(uint32_t* key, uint32_t* pos, uint64_t pop_size, uint32_t size, uint64_t* out_idx);
 int dnaf_mt_characteristic_polynomial(uint64_t* words312, int* degree);
 int dnaf_bgzf_tables_from_histogram(const uint64_t* lit_hist, const uint64_t* match_hist, uint64_t n_eob, void* out,
                                     uint64_t out_cap, uint64_t* size);

@@ -164,3 +164,34 @@ def test_shard_files_are_appended_in_order(tmp_path):
             cli._append_file(out, str(tmp_path / ("shard%d" % k)))
         out.write(b"EOF")
     assert out_path.read_bytes() == b"header" + b"".join(parts) + b"EOF"
+
+
+def test_numpy_legacy_choice_replay_is_numpy():
+    """dnaf_numpy_legacy_choice (the reference's deleterious picks, pop_factory.py:576, without shuffling the whole id list):
+    the same indices as numpy.random.choice(n, k, replace=False) and the same generator state afterwards, from any
+    position in the stream, across block boundaries of the generator and powers of two of n."""
+    import numpy
+
+    from dna_factory_amd import capi
+
+    rs = np.random.RandomState(5)
+    cases = [(1, 1), (2, 1), (2, 2), (3, 2), (10, 3), (7, 7), (623, 2), (624, 5), (625, 3), (1000, 10), (65535, 4), (65536, 5), (65537, 4),
+             (1000003, 10)] + [(int(rs.randint(1, 300000)), int(rs.randint(1, 12))) for _ in range(20)]
+    for n, k in cases:
+        k = min(k, n)
+        for pre in (0, 1, 623, 624, 625, int(rs.randint(0, 3000))):
+            seed = int(rs.randint(0, 2**31))
+            numpy.random.seed(seed)
+            numpy.random.bytes(4 * pre)
+            want = numpy.random.choice(n, k, replace=False)
+            want_state = numpy.random.get_state()
+            follow = numpy.random.rand(3)
+            numpy.random.seed(seed)
+            numpy.random.bytes(4 * pre)
+            got = capi.numpy_legacy_choice(n, k)
+            st = numpy.random.get_state()
+            assert np.array_equal(got, want), (n, k, pre)
+            assert st[2] == want_state[2] and np.array_equal(st[1], want_state[1]), (n, k, pre)
+            assert np.array_equal(numpy.random.rand(3), follow)
+    with pytest.raises(ValueError):
+        capi.numpy_legacy_choice(3, 4)  # numpy's own error for a sample larger than the population
