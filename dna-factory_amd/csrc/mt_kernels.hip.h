@@ -97,74 +97,127 @@ __device__ __forceinline__ uint32_t pick53(uint64_t r, uint64_t t0, uint64_t t1,
 
 __device__ __forceinline__ uint64_t roll53(uint32_t a, uint32_t b) { return ((uint64_t)(a >> 5) << 26) | (uint64_t)(b >> 6); }
 
-// One wave: the next block.  The state is regenerated in place in the three dependent phases of the
-// recurrence (words 0..226 need only old words; 227..453 need the new words 0..226; 454..622 need the
-// new words 227..395, and word 623 the new words 396 and 0).  Inside a phase nothing depends on anything
-// else written in that phase, so all of a phase's LDS reads are issued before its writes: three latency
-// exposures per block instead of ten.  Each new word is also tempered into the output ring at
-// ring[(head + i) mod MT_RING].  The code is branch-free: lanes past the end of a phase read a valid
-// word and write to a spare slot behind each array.
-template <uint32_t LO, uint32_t HI>
-__device__ __forceinline__ void mt_wave_phase(uint32_t* st, uint32_t* ring, uint32_t head, uint32_t lane)
+// Constants of the recurrence and the tempering kept in SGPRs behind an opaque asm, so that every and-xor / select pair
+// is one v_bitop3_b32 with a scalar operand (as literals they cost a separate v_and each: VOP3 takes no literal on gfx9).
+struct MtConsts { uint32_t upper, matrix, c1, c2; };
+__device__ __forceinline__ MtConsts mt_consts()
 {
-    constexpr uint32_t STEPS = (HI - LO + 63u) / 64u;
-    constexpr bool OLD_M = HI <= MTN - MTM; // word i + 397 is still the old one
-    uint32_t v[STEPS];
-#pragma unroll
-    for (uint32_t s = 0; s < STEPS; ++s) {
-        const uint32_t i = min(LO + 64u * s + lane, HI - 1u);
-        const uint32_t i1 = HI == MTN ? 0u : i + 1u; // only the phase of word 623 wraps
-        const uint32_t im = OLD_M ? i + MTM : i - (MTN - MTM);
-        v[s] = st[im] ^ mt_twist(st[i], st[i1]);
-    }
-    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (uint32_t s = 0; s < STEPS; ++s) {
-        const uint32_t i = LO + 64u * s + lane;
-        const bool ok = i < HI;
-        uint32_t h = head + i;
-        h = h >= MT_RING ? h - MT_RING : h;
-        st[ok ? i : MTN] = v[s];                 // st[MTN] and ring[MT_RING] are spare slots
-        ring[ok ? h : MT_RING] = mt_temper(v[s]);
-    }
-    __builtin_amdgcn_wave_barrier();
+    MtConsts k{0x80000000u, 0x9908B0DFu, 0x9D2C5680u, 0xEFC60000u};
+    asm volatile("" : "+s"(k.upper), "+s"(k.matrix), "+s"(k.c1), "+s"(k.c2));
+    return k;
+}
+// (a & c) ^ b in one instruction; the compiler fuses this pair only in some places
+__device__ __forceinline__ uint32_t and_xor(uint32_t a, uint32_t c, uint32_t b)
+{
+    uint32_t r;
+    asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0x6c" : "=v"(r) : "v"(a), "v"(b), "s"(c));
+    return r;
+}
+__device__ __forceinline__ uint32_t mt_twist_k(uint32_t s0, uint32_t s1, uint32_t sm, const MtConsts& k)
+{
+    uint32_t y;                                                          // top bit of s0, the rest of s1
+    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(y) : "s"(k.upper), "v"(s0), "v"(s1));
+    const uint32_t mag = (uint32_t)((int32_t)(s1 << 31) >> 31);          // all ones when s1 is odd: v_bfe_i32
+    return and_xor(mag, k.matrix, sm) ^ (y >> 1);
+}
+__device__ __forceinline__ uint32_t mt_temper_k(uint32_t y, const MtConsts& k)
+{
+    y ^= y >> 11;
+    y = and_xor(y << 7, k.c1, y);
+    y = and_xor(y << 15, k.c2, y);
+    y ^= y >> 18;
+    return y;
 }
 
-__device__ __forceinline__ void mt_wave_next_block(uint32_t* st, uint32_t* ring, uint32_t head, uint32_t lane)
+// One wave: the next block, regenerated in place in ten batches of 64 consecutive words (the last one 48).  Batch b needs
+// the old words 64b .. 64b+64 (the last of them is overwritten by batch b+1, later in program order) and word i+397, which
+// is old up to i = 226 and otherwise the new word i-227 of a batch at least three back; word 623 needs the new word 0.
+// All addresses are `lane + constant` except in the batch where i+397 wraps and for word 623's neighbour: those two index
+// vectors (im3, i1_9) are computed once per kernel.  Each new word is tempered into ringw[i]: the caller passes the slot's
+// first word (slots are 624 words apart, a block never wraps inside the ring).
+// orders this wave's LDS traffic for the compiler (the hardware keeps one wave's LDS operations in order by itself)
+__device__ __forceinline__ void mt_wave_sync()
 {
-    mt_wave_phase<0, 227>(st, ring, head, lane);
-    mt_wave_phase<227, 454>(st, ring, head, lane);
-    mt_wave_phase<454, 623>(st, ring, head, lane);
-    mt_wave_phase<623, 624>(st, ring, head, lane); // needs the new word 0
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+__device__ __forceinline__ void mt_wave_next_block(uint32_t* st, uint32_t* ringw, uint32_t lane, uint32_t im3, uint32_t i1_9,
+                                                   const MtConsts& k)
+{
+    uint32_t* sp = st + lane;
+    uint32_t* rw = ringw + lane;
+    // The lanes talk to each other through `st`, which the compiler cannot see (to one thread all these addresses are
+    // distinct): a wave barrier per batch keeps the memory operations of different batches in program order.  The reads of
+    // batch b+1 depend on nothing batch b writes, so they are issued before batch b's arithmetic and land behind it.
+    uint32_t s0 = sp[0], s1 = sp[1], sm = sp[MTM];
+#pragma unroll
+    for (uint32_t b = 0; b < 10u; ++b) {
+        mt_wave_sync();
+        uint32_t n0 = 0, n1 = 0, nm = 0;
+        if (b < 8u || (b == 8u && lane < 48u)) {
+            const uint32_t c = b + 1u;
+            n0 = sp[64u * c];
+            n1 = c < 9u ? sp[64u * c + 1u] : st[i1_9];
+            nm = c < 3u ? sp[64u * c + MTM] : (c == 3u ? st[im3] : sp[64u * c - (MTN - MTM)]);
+        }
+        if (b < 9u || lane < 48u) {
+            const uint32_t v = mt_twist_k(s0, s1, sm, k);
+            sp[64u * b] = v;
+            rw[64u * b] = mt_temper_k(v, k);
+        }
+        s0 = n0; s1 = n1; sm = nm;
+    }
+    mt_wave_sync();
+}
+
+// the 53-bit numerator r = hi * 2^26 + lo (hi = a >> 5, lo = b >> 6) as the 64-bit number hi * 2^32 + lo: the order of two
+// such numbers is the order of the numerators, so `r > t` is one 64-bit compare and nothing has to be assembled
+__device__ __forceinline__ uint64_t mt_roll_key(uint32_t a, uint32_t b) { return ((uint64_t)(a >> 5) << 32) | (uint64_t)(b >> 6); }
+__device__ __forceinline__ uint64_t mt_thr_key(uint64_t t) { return ((t >> 26) << 32) | (t & 0x3FFFFFFull); }
+
+// One lane = one SAMPLE here (the Philox kernels give a lane four): a step of the row loop takes 64 samples = 256 consecutive
+// words of the stream, lane l reads the aligned quad of words of sample sb + l from the ring -- consecutive lanes, consecutive
+// quads: no LDS bank conflicts (with four samples per lane the 64-byte lane stride made the ring reads 4-way conflicted and
+// the per-lane packing cost more instructions than generating the numbers) -- and the comparisons come out as wave masks, from
+// which the packed bytes are cut directly.
+//
+// Ring: three slots of 624 tempered words; a block is always written to a whole slot.  The first block is used from word
+// start_off on, so the consumer's quads start at indices = start_off (mod 4): the ring is laid into its storage shifted by
+// (-start_off) mod 4 words, which makes every quad 16-byte aligned, and the first three words are mirrored behind the end
+// for the one quad per turn that straddles it.
 template <bool TEXT, bool PACKED>
 __global__ __launch_bounds__(64) void mt_rowgen_kernel(const MtGenParams mp)
 {
     __shared__ uint32_t st[MTN + 1];
-    __shared__ __attribute__((aligned(16))) uint32_t ring[MT_RING + 4];
+    __shared__ __attribute__((aligned(16))) uint32_t ring_store[4 + MT_RING + 4];
     const GenParams& p = mp.g;
     const uint32_t lane = threadIdx.x;
     const uint64_t wave = blockIdx.x;
     const uint64_t row_lo = mp.wave0_row + wave * mp.rows_per_wave; // local row index of this wave's first row
     if (row_lo >= p.n_rows) return;
     const uint64_t row_hi = min(p.n_rows, row_lo + mp.rows_per_wave);
+    const MtConsts K = mt_consts();
+    uint32_t* ring = ring_store + ((4u - (mp.start_off & 3u)) & 3u);
+    // index vectors of the two irregular reads of a block (mt_wave_next_block)
+    const uint32_t im3 = 192u + lane + MTM >= MTN ? 192u + lane + MTM - MTN : 192u + lane + MTM;
+    const uint32_t i1_9 = lane == 47u ? 0u : 577u + lane;
 
     for (uint32_t i = lane; i < MTN; i += 64u) st[i] = mp.states[wave * MTN + i];
-    __builtin_amdgcn_wave_barrier();
-    // ring bookkeeping in words; all wave-uniform
-    uint32_t head = 0, tail = 0, avail = 0;
-    // the first block is used from start_off on
-    for (uint32_t i = mp.start_off + lane; i < MTN; i += 64u) ring[i - mp.start_off] = mt_temper(st[i]);
-    head = avail = MTN - mp.start_off;
-    __builtin_amdgcn_wave_barrier();
+    mt_wave_sync();
+    // ring bookkeeping in words; all wave-uniform.  The first block sits in slot 0 at its own offsets.
+    for (uint32_t i = mp.start_off + lane; i < MTN; i += 64u) ring[i] = mt_temper_k(st[i], K);
+    uint32_t head = MTN, tail = mp.start_off, avail = MTN - mp.start_off;
+    mt_wave_sync();
 
-    const uint32_t S = p.S, G = p.G;
+    const uint32_t S = p.S;
     const uint32_t row_words = 4u * S;
+    const uint32_t row_pk_bytes = p.W * 4u;
     for (uint64_t row_local = row_lo; row_local < row_hi; ++row_local) {
         const RowRec rec = p.recs[p.row_begin + row_local];
         const uint64_t* thr = mp.thr53 + (p.row_begin + row_local) * 3u;
-        const uint64_t t0 = thr[0], t1 = thr[1], t2 = thr[2];
+        const uint64_t T0 = mt_thr_key(thr[0]), T1 = mt_thr_key(thr[1]), T2 = mt_thr_key(thr[2]);
         uint8_t* row_text = p.text + (rec.text_off - p.text_base);
         if (TEXT) {
             const uint8_t* src = p.prefix + rec.prefix_off;
@@ -173,80 +226,97 @@ __global__ __launch_bounds__(64) void mt_rowgen_kernel(const MtGenParams mp)
         }
         uint8_t* cells = row_text + rec.prefix_len;
         uint8_t* prow = p.packed + row_local * p.packed_pitch;
-        const uint8_t* frow = rec.slot >= 0 ? p.forced + (uint64_t)rec.slot * G : nullptr;
+        const uint8_t* frow = rec.slot >= 0 ? p.forced + (uint64_t)rec.slot * p.G : nullptr;
         const uint32_t cls = rec.cls;
+        const bool multi = rec.n_alleles > 2;
+        const bool plain = cls == 0u && !multi && !frow; // biallelic autosomal row without forced cells: the short step
         uint32_t consumed = 0; // words of this row consumed so far
-        for (uint32_t gb = 0; gb < G; gb += 64u) {
-            const uint32_t need = min(1024u, row_words - consumed);
+        for (uint32_t sb = 0; sb < S; sb += 64u) {
+            const uint32_t need = min(256u, row_words - consumed);
             while (avail < need) { // wave-uniform
-                mt_wave_next_block(st, ring, head, lane);
-                head += MTN;
-                if (head >= MT_RING) head -= MT_RING;
+                mt_wave_next_block(st, ring + head, lane, im3, i1_9, K);
+                if (head == 0u && lane < 3u) ring[MT_RING + lane] = ring[lane];
+                head = head == 2u * MTN ? 0u : head + MTN;
                 avail += MTN;
-                __builtin_amdgcn_wave_barrier();
+                mt_wave_sync();
             }
-            const uint32_t g = gb + lane;
-            if (g < G) {
-                // the group's 16 words = 4 aligned quads (tail is a multiple of 4 words); a quad never straddles
-                // the ring end.  Quads past the row's last sample may hold stale words: they are never used.
-                uint32_t q0 = tail + 16u * lane, q1 = q0 + 4u, q2 = q0 + 8u, q3 = q0 + 12u;
-                q0 = q0 >= MT_RING ? q0 - MT_RING : q0; q1 = q1 >= MT_RING ? q1 - MT_RING : q1;
-                q2 = q2 >= MT_RING ? q2 - MT_RING : q2; q3 = q3 >= MT_RING ? q3 - MT_RING : q3;
-                const uint4 w0 = *reinterpret_cast<const uint4*>(ring + q0), w1 = *reinterpret_cast<const uint4*>(ring + q1);
-                const uint4 w2 = *reinterpret_cast<const uint4*>(ring + q2), w3 = *reinterpret_cast<const uint4*>(ring + q3);
-                uint32_t a[4], b[4];
-                a[0] = pick53(roll53(w0.x, w0.y), t0, t1, t2); b[0] = pick53(roll53(w0.z, w0.w), t0, t1, t2);
-                a[1] = pick53(roll53(w1.x, w1.y), t0, t1, t2); b[1] = pick53(roll53(w1.z, w1.w), t0, t1, t2);
-                a[2] = pick53(roll53(w2.x, w2.y), t0, t1, t2); b[2] = pick53(roll53(w2.z, w2.w), t0, t1, t2);
-                a[3] = pick53(roll53(w3.x, w3.y), t0, t1, t2); b[3] = pick53(roll53(w3.z, w3.w), t0, t1, t2);
-                if (frow) { // forced genotype 1/1, pop_factory.py:495-499
-                    const uint32_t f = frow[g];
-#pragma unroll
-                    for (int k = 0; k < 4; ++k)
-                        if ((f >> k) & 1u) a[k] = b[k] = 1u;
+            uint32_t q = tail + 4u * lane;
+            q = q >= MT_RING ? q - MT_RING : q;
+            // 16-byte aligned by the ring's shift; lanes past the row's end read words that are not used
+            const uint4 w = *reinterpret_cast<const uint4*>(__builtin_assume_aligned(ring + q, 16));
+            const uint64_t va = mt_roll_key(w.x, w.y), vb = mt_roll_key(w.z, w.w);
+            if (plain && sb + 64u < S) {
+                // all 64 samples live, none of them the row's last
+                const uint64_t A = __ballot(va > T0), B = __ballot(vb > T0);
+                if (TEXT) {
+                    const uint32_t cell = DIPLOID_CELL(0u, 0u, 0x09u) + (va > T0 ? 1u : 0u) + (vb > T0 ? 0x10000u : 0u);
+                    store_unaligned<4>(cells + 4ull * sb + 4u * lane, &cell);
                 }
-                uint32_t pk = 0;
-                if (cls == 0u && 4u * g + 4u < S) { // complete autosome group that does not hold the row's last sample
-                    if (TEXT) {
-                        const uint4 w = make_uint4(DIPLOID_CELL(a[0], b[0], 9u), DIPLOID_CELL(a[1], b[1], 9u),
-                                                   DIPLOID_CELL(a[2], b[2], 9u), DIPLOID_CELL(a[3], b[3], 9u));
-                        store_unaligned<16>(cells + 16ull * g, &w);
-                    }
-                    pk = nz(a[0]) | nz(b[0]) << 1 | nz(a[1]) << 2 | nz(b[1]) << 3 | nz(a[2]) << 4 | nz(b[2]) << 5 |
-                         nz(a[3]) << 6 | nz(b[3]) << 7;
-                } else {
-                    const uint32_t male = p.male_nib[g]; // only the sex-chromosome rules need it
-                    uint8_t* dst = cells + (cls == 0u ? 16ull * g : (cls == 1u ? (uint64_t)p.xoff[g] : 8ull * g));
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        const uint32_t i = 4u * g + (uint32_t)k;
-                        if (i < S) {
-                            const uint32_t sep = (i == S - 1u) ? 0x0Au : 0x09u;
-                            const bool is_male = (male >> k) & 1u;
-                            const bool missing = cls == 2u && !is_male;              // pop_factory.py:481-484
-                            const bool haploid = cls >= 2u || (cls == 1u && is_male); // common/snp.py:102-109
-                            if (missing) {
-                                if (TEXT) { const uint16_t h = (uint16_t)HAPLOID_CELL(0x2Eu, sep); store_unaligned<2>(dst, &h); dst += 2; }
-                            } else if (haploid) {
-                                pk |= nz(a[k]) << (2 * k);
-                                if (TEXT) { const uint16_t h = (uint16_t)HAPLOID_CELL(0x30u + a[k], sep); store_unaligned<2>(dst, &h); dst += 2; }
-                            } else {
-                                pk |= (nz(a[k]) | nz(b[k]) << 1) << (2 * k);
-                                if (TEXT) { const uint32_t w = DIPLOID_CELL(a[k], b[k], sep); store_unaligned<4>(dst, &w); dst += 4; }
-                            }
-                        }
+                if (PACKED) {
+                    // even bits from A, odd bits from B: s_bitreplicate doubles every bit, the masks pick the copy
+                    uint64_t a0, a1, b0, b1;
+                    asm("s_bitreplicate_b64_b32 %0, %1" : "=s"(a0) : "s"((uint32_t)A));
+                    asm("s_bitreplicate_b64_b32 %0, %1" : "=s"(a1) : "s"((uint32_t)(A >> 32)));
+                    asm("s_bitreplicate_b64_b32 %0, %1" : "=s"(b0) : "s"((uint32_t)B));
+                    asm("s_bitreplicate_b64_b32 %0, %1" : "=s"(b1) : "s"((uint32_t)(B >> 32)));
+                    const uint64_t p0 = (a0 & 0x5555555555555555ull) | (b0 & 0xAAAAAAAAAAAAAAAAull);
+                    const uint64_t p1 = (a1 & 0x5555555555555555ull) | (b1 & 0xAAAAAAAAAAAAAAAAull);
+                    if (lane == 0u) {
+                        const uint4 pk = make_uint4((uint32_t)p0, (uint32_t)(p0 >> 32), (uint32_t)p1, (uint32_t)(p1 >> 32));
+                        store_unaligned<16>(prow + (sb >> 2), &pk);
                     }
                 }
-                if (PACKED) prow[g] = (uint8_t)pk;
+            } else {
+                const uint32_t i = sb + lane; // this lane's sample
+                const bool live = i < S;
+                // SNPTuples.pick_allele_index (pop_factory.py:92-95): first index whose cumulative frequency is >= the roll
+                uint32_t a = va > T0 ? 1u : 0u, b = vb > T0 ? 1u : 0u;
+                if (multi) { // wave-uniform
+                    a += (va > T1 ? 1u : 0u) + (va > T2 ? 1u : 0u);
+                    b += (vb > T1 ? 1u : 0u) + (vb > T2 ? 1u : 0u);
+                }
+                const uint32_t g = i >> 2, k = i & 3u;
+                if (frow && live && ((frow[g] >> k) & 1u)) a = b = 1u; // forced genotype 1/1, pop_factory.py:495-499
+                bool missing = false, haploid = false;
+                uint32_t male_nib = 0;
+                if (cls != 0u) { // wave-uniform
+                    male_nib = live ? p.male_nib[g] : 0u;
+                    const bool is_male = (male_nib >> k) & 1u;
+                    missing = cls == 2u && !is_male;              // pop_factory.py:481-484
+                    haploid = cls >= 2u || (cls == 1u && is_male); // common/snp.py:102-109
+                }
+                if (PACKED) {
+                    // 2-bit codes of the 64 samples as two wave masks -> 16 bytes; lane j < 16 cuts byte j (samples 4j .. 4j+3)
+                    const uint64_t A = __ballot(live && !missing && a != 0u), B = __ballot(live && !missing && !haploid && b != 0u);
+                    uint32_t x = (uint32_t)(A >> (4u * (lane & 15u))) & 15u, y = (uint32_t)(B >> (4u * (lane & 15u))) & 15u;
+                    x = (x | (x << 2)) & 0x33u; x = (x | (x << 1)) & 0x55u;
+                    y = (y | (y << 2)) & 0x33u; y = (y | (y << 1)) & 0x55u;
+                    const uint32_t first = sb >> 2; // the step's first byte of the row; bytes up to the row's padded length are stored
+                    if (lane < 16u && first + lane < row_pk_bytes) prow[first + lane] = (uint8_t)(x | (y << 1));
+                }
+                if (TEXT && live) {
+                    const uint32_t sep = (i == S - 1u) ? 0x0Au : 0x09u; // "\t".join(...) + "\n", pop_factory.py:508
+                    if (cls == 0u) {
+                        const uint32_t cell = DIPLOID_CELL(a, b, sep);
+                        store_unaligned<4>(cells + 4ull * i, &cell);
+                    } else {
+                        // X: 2 bytes for a male, 4 for a female; Y / MT: 2 bytes each
+                        const uint32_t before = male_nib & ((1u << k) - 1u);
+                        const uint64_t off = cls == 1u ? (uint64_t)p.xoff[g] + 4u * k - 2u * (uint32_t)__builtin_popcount(before) : 2ull * i;
+                        if (missing) { const uint16_t h = (uint16_t)HAPLOID_CELL(0x2Eu, sep); store_unaligned<2>(cells + off, &h); }
+                        else if (haploid) { const uint16_t h = (uint16_t)HAPLOID_CELL(0x30u + a, sep); store_unaligned<2>(cells + off, &h); }
+                        else { const uint32_t cell = DIPLOID_CELL(a, b, sep); store_unaligned<4>(cells + off, &cell); }
+                    }
+                }
             }
-            __builtin_amdgcn_wave_barrier();
+            mt_wave_sync();
             tail += need;
             if (tail >= MT_RING) tail -= MT_RING;
             avail -= need;
             consumed += need;
         }
-        if (PACKED)
-            for (uint32_t g = G + lane; g < p.W * 4u; g += 64u) prow[g] = 0; // pad bytes of the packed row
+        if (PACKED) // bytes of the packed row that no step reached (S = 0, or a row length that is a multiple of 64 samples plus pad)
+            for (uint32_t gq = ((S + 63u) / 64u) * 16u + lane; gq < row_pk_bytes; gq += 64u) prow[gq] = 0;
     }
 }
 
