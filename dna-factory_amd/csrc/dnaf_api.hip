@@ -93,7 +93,7 @@ struct dnaf_ctx {
     uint32_t* d_mt_tmp = nullptr;
     uint64_t mt_cap = 0, mt_lo = 0, mt_n = 0;
     bool mt_valid = false;
-    std::map<uint64_t, uint64_t*> mt_polys; // jump distance in words -> device polynomial (312 x u64)
+    std::map<uint64_t, uint32_t*> mt_polys; // jump distance in words -> device list of the polynomial's set bits (mt_jump_kernel)
 
     // BGZF encoder
     dnaf::BgzfTables* d_tables = nullptr;
@@ -547,16 +547,29 @@ static dnaf::MtJumper& mt_jumper()
 
 static uint64_t gcd_u64(uint64_t a, uint64_t b) { while (b) { const uint64_t t = a % b; a = b; b = t; } return a; }
 
-// device polynomial x^(J-1) mod phi for a jump of J >= 1 words (cached per distance)
-static int mt_poly_for(dnaf_ctx* c, uint64_t J, const uint64_t** out)
+// x^(J-1) mod phi as the list of set bits mt_jump_kernel reads (layout there)
+static std::vector<uint32_t> mt_poly_list(const dnaf::MtPoly& g)
+{
+    std::vector<uint32_t> l(dnaf::MT_POLY_LIST_HEAD, 0u);
+    l.reserve(dnaf::MT_POLY_LIST_MAX);
+    for (uint32_t w = 0; w < 312u; ++w)
+        for (uint64_t bits = g.w[w]; bits; bits &= bits - 1) l.push_back(4u * (64u * w + (uint32_t)__builtin_ctzll(bits)));
+    while ((l.size() - dnaf::MT_POLY_LIST_HEAD) % 16u) l.push_back(4u * dnaf::MT_PAD_WORD);
+    l[0] = (uint32_t)((l.size() - dnaf::MT_POLY_LIST_HEAD) / 16u);
+    return l;
+}
+
+// device list of x^(J-1) mod phi for a jump of J >= 1 words (cached per distance)
+static int mt_poly_for(dnaf_ctx* c, uint64_t J, const uint32_t** out)
 {
     auto it = c->mt_polys.find(J);
     if (it == c->mt_polys.end()) {
         dnaf::MtPoly g;
         mt_jumper().xpow_mod(J - 1, &g);
-        uint64_t* d = nullptr;
-        HIP_TRY(c, hipMalloc((void**)&d, sizeof g.w));
-        hipError_t e = hipMemcpy(d, g.w, sizeof g.w, hipMemcpyHostToDevice);
+        const std::vector<uint32_t> l = mt_poly_list(g);
+        uint32_t* d = nullptr;
+        HIP_TRY(c, hipMalloc((void**)&d, l.size() * sizeof(uint32_t)));
+        hipError_t e = hipMemcpy(d, l.data(), l.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
         if (e != hipSuccess) { (void)hipFree(d); return fail(c, DNAF_ERR_HIP, "mt_poly_for: %s", hipGetErrorString(e)); }
         it = c->mt_polys.emplace(J, d).first;
     }
@@ -590,7 +603,7 @@ static int mt_prepare_states(dnaf_ctx* c, uint64_t lo, uint64_t n, uint64_t D)
         HIP_TRY(c, hipMalloc((void**)&c->d_mt_base, sizeof c->mt_key));
         HIP_TRY(c, hipMemcpy(c->d_mt_base, c->mt_key, sizeof c->mt_key, hipMemcpyHostToDevice));
     }
-    const uint64_t* poly = nullptr;
+    const uint32_t* poly = nullptr;
     if (c->mt_valid && lo == c->mt_lo + c->mt_n && n <= c->mt_n) {
         // the next tile of a sequential sweep: every cached state advances by the same distance
         if (int rc = mt_poly_for(c, c->mt_n * D * 624, &poly)) return rc;

@@ -9,10 +9,9 @@
 // polynomial of mt_jump.h evaluated as a correlation over the word sequence, in LDS).
 //
 // mt_rowgen_kernel: one wave per workgroup.  The wave keeps the generator state (624 words) and a
-// ring of tempered output words in LDS, regenerates blocks in the three dependent phases of the
-// recurrence (227 / 227 / 170 words, 64 lanes wide), and consumes 16 words per lane per iteration:
-// the 8 rolls of a group of 4 samples, exactly the lane mapping of the Philox kernel.  Cell rules,
-// text layout and packed codes are those of rowgen_kernels.hip.h.
+// ring of tempered output words in LDS, regenerates a block in ten batches of 64 consecutive words,
+// and consumes 256 words per step: lane l takes the four words (two rolls) of sample 64 k + l.  Cell
+// rules, text layout and packed codes are those of rowgen_kernels.hip.h.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -40,15 +39,24 @@ __device__ __forceinline__ uint32_t mt_temper(uint32_t y)
     return y;
 }
 
-// dst[j] = window J words after src[map ? map[j] : j], for the polynomial g = x^(J-1) mod phi given as
-// 312 x u64 coefficient words: dst[j][q] = XOR over set bits i of x[i + q + 1].  One workgroup per jump.
+// dst[j] = window J words after src[map ? map[j] : j], for the polynomial g = x^(J-1) mod phi:
+// dst[j][q] = XOR over set bits i of g of x[i + q + 1].  One workgroup per jump.  The polynomial arrives as the list of
+// its set bits (mt_poly_list: word 0 = number of 16-entry groups, entries from word 16 on, each the BYTE offset 4 i, the
+// last group padded with offsets of words that are zero): the positions are wave-uniform, so they come through scalar
+// loads sixteen at a time and every term costs one address add, one LDS read and one xor.  (Scanning the bits of the
+// coefficient words in the kernel cost ~8 scalar instructions per term, on the one scalar unit a CU's SIMDs share:
+// the kernel was bound by that, 11.2 ms for 6410 jumps.)
+constexpr uint32_t MT_POLY_LIST_HEAD = 16;                                     // words before the first entry
+constexpr uint32_t MT_POLY_LIST_MAX = MT_POLY_LIST_HEAD + ((19937 + 15) / 16) * 16; // words of a full list
+constexpr uint32_t MT_PAD_WORD = MT_SEQ_WORDS;                                 // x[MT_PAD_WORD + q + 1] = 0 for q < 624
 __global__ __launch_bounds__(640) void mt_jump_kernel(const uint32_t* src, const uint32_t* map, uint32_t* dst,
-                                                      const uint64_t* poly)
+                                                      const uint32_t* __restrict__ plist)
 {
-    __shared__ uint32_t x[MT_SEQ_WORDS];
+    __shared__ uint32_t x[MT_SEQ_WORDS + MTN + 1];
     const uint32_t j = blockIdx.x, t = threadIdx.x;
     const uint32_t* s = src + (uint64_t)(map ? map[j] : j) * MTN;
     if (t < MTN) x[t] = s[t];
+    for (uint32_t k = MT_SEQ_WORDS + t; k < MT_SEQ_WORDS + MTN + 1u; k += 640u) x[k] = 0;
     __syncthreads();
     // the sequence continues by the recurrence; word k needs k-624, k-623, k-227: 227 words per step
     for (uint32_t k0 = MTN; k0 < MT_SEQ_WORDS; k0 += 227u) {
@@ -57,26 +65,18 @@ __global__ __launch_bounds__(640) void mt_jump_kernel(const uint32_t* src, const
         __syncthreads();
     }
     if (t < MTN) {
-        uint32_t acc = 0;
-        const uint32_t* xt = x + t + 1u;
-        for (uint32_t w = 0; w < 312u; ++w) {
-            uint64_t bits = poly[w]; // wave-uniform: the positions are scalar, the loads are independent
-            const uint32_t* xw = xt + 64u * w;
-            while (bits) {
-                uint32_t idx[8];
+        const uint32_t groups = plist[0];
+        const uint32_t* e = plist + MT_POLY_LIST_HEAD;
+        const uint8_t* xt = reinterpret_cast<const uint8_t*>(x + t + 1u);
+        uint32_t acc0 = 0, acc1 = 0, acc2 = 0, acc3 = 0;
+        for (uint32_t gk = 0; gk < groups; ++gk, e += 16) {
+            uint32_t v[16];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    idx[u] = bits ? (uint32_t)__builtin_ctzll(bits) : 0xFFFFFFFFu;
-                    bits &= bits - 1; // stays 0 once empty
-                }
-                uint32_t val[8];
+            for (int u = 0; u < 16; ++u) v[u] = *reinterpret_cast<const uint32_t*>(xt + e[u]);
 #pragma unroll
-                for (int u = 0; u < 8; ++u) val[u] = idx[u] != 0xFFFFFFFFu ? xw[idx[u]] : 0u;
-#pragma unroll
-                for (int u = 0; u < 8; ++u) acc ^= val[u];
-            }
+            for (int u = 0; u < 16; u += 4) { acc0 ^= v[u]; acc1 ^= v[u + 1]; acc2 ^= v[u + 2]; acc3 ^= v[u + 3]; }
         }
-        dst[(uint64_t)j * MTN + t] = acc;
+        dst[(uint64_t)j * MTN + t] = (acc0 ^ acc1) ^ (acc2 ^ acc3);
     }
 }
 
