@@ -39,7 +39,7 @@ def parse_args():
     ap.add_argument("--table-seed", type=int, default=20261004, help="seed of the synthetic SNP / sample tables")
     ap.add_argument("--what", choices=["text+packed", "text", "packed"], default="text+packed")
     ap.add_argument("--rng", choices=["philox", "mt19937"], default="philox",
-                    help="row RNG; mt19937 = numpy-compatible stream (tile rows are rounded down to its row quantum)")
+                    help="row RNG; mt19937 = numpy-compatible stream (tile rows are rounded to whole rounds of 4096 waves of its row quantum)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target duration of the CPU baseline sample (0 = skip)")
     ap.add_argument("--bgzf-tiles", type=int, default=2,
                     help="after the timed region, compress this many tiles with the on-GPU BGZF encoder and report "
@@ -188,7 +188,12 @@ class _Rank:
         self.gen = gen = RowGenerator(device=device, seed=a.seed, rng=a.rng)
         gen.set_samples(self.st)
         q = gen.row_quantum
-        self.tile_rows = max(q, a.tile_rows // q * q)
+        if a.rng == "mt19937" and q > 1:
+            # a wave owns q rows and holds 10 KB of LDS: 4096 waves are resident at once, so whole rounds of 4096 waves
+            q *= 4096 if a.tile_rows >= 4096 * q else 1
+            self.tile_rows = max(q, (a.tile_rows + q // 2) // q * q)
+        else:
+            self.tile_rows = max(q, a.tile_rows // q * q)
         rows = max(self.tile_rows, rows // self.tile_rows * self.tile_rows)
         if rows < len(tb):
             tb = tb.slice(0, rows)

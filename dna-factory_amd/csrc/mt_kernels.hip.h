@@ -22,7 +22,7 @@ namespace dnaf {
 
 constexpr uint32_t MTN = 624, MTM = 397;
 constexpr uint32_t MT_SEQ_WORDS = 19937 + 624 + 8; // words of sequence a jump correlates over
-constexpr uint32_t MT_RING = 1872;                 // 3 blocks of tempered words (multiple of 16)
+constexpr uint32_t MT_RING = 1872;                 // 3 slots of one block of tempered words each (2 would do: no faster)
 
 __device__ __forceinline__ uint32_t mt_twist(uint32_t a, uint32_t b)
 {
@@ -183,7 +183,9 @@ __device__ __forceinline__ uint64_t mt_thr_key(uint64_t t) { return ((t >> 26) <
 // the per-lane packing cost more instructions than generating the numbers) -- and the comparisons come out as wave masks, from
 // which the packed bytes are cut directly.
 //
-// Ring: three slots of 624 tempered words; a block is always written to a whole slot.  The first block is used from word
+// Ring: three slots of 624 tempered words; a block is always written to a whole slot, and only when fewer than 256 words
+// are left -- those lie in the slot before it.  (Two slots are enough and were measured: 21 instead of 16 waves per CU, no
+// faster -- the kernel runs at a power-limited clock, 2.0-2.2 GHz, with its vector units 75 % busy.)  The first block is used from word
 // start_off on, so the consumer's quads start at indices = start_off (mod 4): the ring is laid into its storage shifted by
 // (-start_off) mod 4 words, which makes every quad 16-byte aligned, and the first three words are mirrored behind the end
 // for the one quad per turn that straddles it.
@@ -236,7 +238,7 @@ __global__ __launch_bounds__(64) void mt_rowgen_kernel(const MtGenParams mp)
             while (avail < need) { // wave-uniform
                 mt_wave_next_block(st, ring + head, lane, im3, i1_9, K);
                 if (head == 0u && lane < 3u) ring[MT_RING + lane] = ring[lane];
-                head = head == 2u * MTN ? 0u : head + MTN;
+                head = head + MTN == MT_RING ? 0u : head + MTN;
                 avail += MTN;
                 mt_wave_sync();
             }
