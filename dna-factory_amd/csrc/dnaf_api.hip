@@ -71,6 +71,8 @@ struct dnaf_ctx {
     uint64_t n_rows = 0;
     RowRec* d_recs = nullptr;
     uint8_t* d_prefix = nullptr;
+    uint8_t* d_prefix_fixed = nullptr; // short rows: the prefixes once more, prefix_stride bytes apart (rowmix_kernel)
+    uint32_t prefix_stride = 0;
     std::vector<uint64_t> h_text_off; // [n_rows+1]
 
     // outputs
@@ -136,7 +138,7 @@ struct dnaf_ctx {
     uint64_t min_run_waves = 8192;   // fewer runs than this and long rows: the segment form fills the GPU better
     uint32_t force_rpw = 0;          // DNAF_ROWS_PER_WAVE: rows per wave of the line-owning form (tests)
     bool no_rowmix = false;          // DNAF_NO_ROWMIX=1: never the short-row form (A/B runs)
-    uint32_t mix_max_groups = 150;   // rows of fewer groups than this (S < 600) take the short-row form (measured crossover)
+    uint32_t mix_max_groups = 420;   // rows of fewer groups than this (S < 1,680) take the short-row form (measured crossover)
     uint32_t run_lds_pad = DNAF_RUN_LDS_PAD_DEFAULT; // unused dynamic LDS per workgroup of rowrun_kernel: caps the workgroups per CU
 };
 
@@ -206,7 +208,7 @@ int dnaf_create(int device, dnaf_ctx** out)
     if (const char* s = getenv("DNAF_FORCE_SEGMENTS")) c->force_segments = atoi(s) != 0;
     if (const char* s = getenv("DNAF_MIN_RUN_WAVES")) c->min_run_waves = strtoull(s, nullptr, 10);
     if (const char* s = getenv("DNAF_NO_ROWMIX")) c->no_rowmix = atoi(s) != 0;
-    if (const char* s = getenv("DNAF_MIX_MAX_GROUPS")) c->mix_max_groups = (uint32_t)strtoul(s, nullptr, 10);
+    if (const char* s = getenv("DNAF_MIX_MAX_GROUPS")) c->mix_max_groups = std::min<uint32_t>((uint32_t)strtoul(s, nullptr, 10), dnaf::MIX_MAX_GROUPS);
     if (const char* s = getenv("DNAF_RUN_LDS_PAD")) c->run_lds_pad = (uint32_t)std::min<unsigned long long>(strtoull(s, nullptr, 10), 48u << 10);
     if (const char* s = getenv("DNAF_ROWS_PER_WAVE")) c->force_rpw = (uint32_t)std::min<unsigned long long>(strtoull(s, nullptr, 10), 1u << 20);
     if (const char* s = getenv("DNAF_SEG_ITERS")) {
@@ -228,6 +230,7 @@ int dnaf_destroy(dnaf_ctx* c)
     dev_free(c->d_forced);
     dev_free(c->d_recs);
     dev_free(c->d_prefix);
+    dev_free(c->d_prefix_fixed);
     dev_free(c->d_text);
     dev_free(c->d_packed);
     for (void* hp : c->h_pinned) if (hp) (void)hipHostFree(hp);
@@ -416,6 +419,7 @@ int dnaf_set_snps(dnaf_ctx* c, const dnaf_snp_table* t)
     c->have_snps = c->have_output = false;
     dev_free(c->d_recs);
     dev_free(c->d_prefix);
+    dev_free(c->d_prefix_fixed);
     dev_free(c->d_thr53);
     c->thr53_ok = true;
     std::vector<RowRec> recs;
@@ -429,7 +433,8 @@ int dnaf_set_snps(dnaf_ctx* c, const dnaf_snp_table* t)
     const uint64_t S = c->S;
     const uint64_t cells_len[4] = {S ? 4 * S : 1, S ? c->x_row_bytes : 1, S ? 2 * S : 1, S ? 2 * S : 1};
     const uint64_t pbase = n ? t->prefix_off[0] : 0;
-    uint64_t off = 0;
+    uint64_t off = 0, max_plen = 0;
+    c->prefix_stride = 0;
     for (uint64_t j = 0; j < n; ++j) {
         RowRec& r = recs[(size_t)j];
         const uint32_t na = t->n_alleles[j], cls = t->chrom_class[j];
@@ -452,6 +457,7 @@ int dnaf_set_snps(dnaf_ctx* c, const dnaf_snp_table* t)
             return fail(c, DNAF_ERR_UNSUPPORTED, "dnaf_set_snps: row %llu prefix too long / prefix blob over 4 GiB", (unsigned long long)j);
         r.prefix_off = (uint32_t)poff;
         r.prefix_len = (uint16_t)plen;
+        max_plen = std::max(max_plen, plen);
         r.text_off = off;
         auto it = c->n_slots ? c->slot_of.find(t->snp_id[j]) : c->slot_of.end();
         r.slot = it == c->slot_of.end() ? -1 : it->second;
@@ -471,7 +477,22 @@ int dnaf_set_snps(dnaf_ctx* c, const dnaf_snp_table* t)
         if (e != hipSuccess) { // no half-loaded table is left behind
             dev_free(c->d_recs);
             dev_free(c->d_prefix);
+    dev_free(c->d_prefix_fixed);
             return fail(c, e == hipErrorOutOfMemory ? DNAF_ERR_OOM : DNAF_ERR_HIP, "dnaf_set_snps: %s", hipGetErrorString(e));
+        }
+    }
+    // short rows: a second copy of the fixed columns at a fixed stride, so that a wave of rowmix_kernel can ask for them
+    // without having its rows' records first (rowmix_kernels.hip.h).  Skipped when a prefix is longer than 64 bytes.
+    if (n && c->S && c->G < c->mix_max_groups && c->Wp == c->W && max_plen <= 64) {
+        const uint32_t stride = (uint32_t)std::max<uint64_t>(16, (max_plen + 15) / 16 * 16);
+        if (hipMalloc((void**)&c->d_prefix_fixed, n * stride + 64) == hipSuccess) {
+            hipLaunchKernelGGL(dnaf::prefix_fix_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, c->stream, (const RowRec*)c->d_recs,
+                               (const uint8_t*)c->d_prefix, c->d_prefix_fixed, n, stride);
+            if (hipGetLastError() == hipSuccess && hipStreamSynchronize(c->stream) == hipSuccess) c->prefix_stride = stride;
+        }
+        if (!c->prefix_stride) { // optional: the kernel works without it
+            (void)hipGetLastError();
+            dev_free(c->d_prefix_fixed);
         }
     }
     c->n_rows = n;
@@ -667,10 +688,12 @@ static int generate_mt(dnaf_ctx* c, uint64_t row_begin, uint64_t n_rows, uint32_
     }
     if (rec) HIP_TRY(c, hipEventRecord(c->evs[2 * c->n_timed], c->stream));
     if (int rc = mt_prepare_states(c, rng_row / R, n_waves, D)) return rc;
-    dnaf::MtGenParams mp;
+    dnaf::MtGenParams mp{};
     GenParams& p = mp.g;
     p.recs = c->d_recs;
     p.prefix = c->d_prefix;
+    p.prefix_fixed = c->d_prefix_fixed;
+    p.prefix_stride = c->prefix_stride;
     p.male_nib = c->d_male_nib;
     p.xoff = c->d_xoff;
     p.forced = c->d_forced;
@@ -721,9 +744,11 @@ int dnaf_generate(dnaf_ctx* c, uint64_t row_begin, uint64_t n_rows, uint32_t wha
     if (n_rows == 0) return DNAF_OK;
     if (c->rng_mode == DNAF_RNG_MT19937 && c->S) return generate_mt(c, row_begin, n_rows, what); // S == 0 draws nothing
 
-    GenParams p;
+    GenParams p{};
     p.recs = c->d_recs;
     p.prefix = c->d_prefix;
+    p.prefix_fixed = c->d_prefix_fixed;
+    p.prefix_stride = c->prefix_stride;
     p.male_nib = c->d_male_nib;
     p.xoff = c->d_xoff;
     p.forced = c->d_forced;
@@ -755,7 +780,19 @@ int dnaf_generate(dnaf_ctx* c, uint64_t row_begin, uint64_t n_rows, uint32_t wha
     const bool use_mix = c->S >= 1u && c->Wp == c->W && c->G < c->mix_max_groups && !c->force_segments && !c->no_rowmix;
     if (use_mix) {
         use_runs = false;
-        rpw = (uint32_t)std::min<uint64_t>(64, std::max<uint64_t>(1, (2048 + c->G - 1) / c->G));
+        // up to 64 rows (one lane sets up one row), about 3,000 groups; of the candidates the one whose last trip is
+        // fullest (a wave's last trip costs a whole trip: 41 rows of 50 groups end in a trip of 2)
+        rpw = (uint32_t)std::min<uint64_t>(64, std::max<uint64_t>(1, (3200 + c->G - 1) / c->G));
+        {
+            uint32_t best = rpw;
+            double best_fill = 0;
+            for (uint32_t r = rpw; r >= 1 && r + 16 > rpw; --r) {
+                const uint64_t groups = (uint64_t)r * c->G, trips = (groups + 63) / 64;
+                const double fill = (double)groups / (64.0 * trips);
+                if (fill > best_fill + 1e-9) { best_fill = fill; best = r; }
+            }
+            rpw = best;
+        }
         while (rpw > 1 && n_rows / rpw < 16384) rpw /= 2;
         if (c->force_rpw) rpw = std::min<uint32_t>(c->force_rpw, 64u);
     }
@@ -955,6 +992,17 @@ int dnaf_debug_gtz_profile(unsigned long long* out16)
     unsigned long long z[16] = {0};
     if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(dnaf::gtz_prof), sizeof z) != hipSuccess) return DNAF_ERR_HIP;
     if (hipMemcpyToSymbol(HIP_SYMBOL(dnaf::gtz_prof), z, sizeof z) != hipSuccess) return DNAF_ERR_HIP;
+    return DNAF_OK;
+}
+#endif
+
+#ifdef DNAF_MIX_PROFILE
+// debug builds: read and reset the stage clock of rowmix_kernel (tools/mix_stage_profile.py)
+int dnaf_debug_mix_profile(unsigned long long* out16)
+{
+    unsigned long long z[16] = {0};
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(dnaf::mix_prof), sizeof z) != hipSuccess) return DNAF_ERR_HIP;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(dnaf::mix_prof), z, sizeof z) != hipSuccess) return DNAF_ERR_HIP;
     return DNAF_OK;
 }
 #endif

@@ -52,6 +52,8 @@ struct GenParams {
     uint32_t S, G, W;          // samples, groups of 4, packed words per row
     uint32_t nseg, seg_groups; // segments per row, groups per segment (multiple of 64)
     uint32_t rows_per_wave;    // rowrun_kernel: whole rows per wave
+    uint32_t prefix_stride;    // rowmix_kernel: bytes per row in prefix_fixed (multiple of 16, <= 64); 0: no such copy
+    const uint8_t* prefix_fixed; // [table rows][prefix_stride] the rows' fixed columns at a fixed stride
 };
 
 #define PHILOX_M0 0xD2511F53u

@@ -13,10 +13,10 @@
 // code of rowrun_kernels.hip.h in between.
 //
 // Same cell rules, RNG lane mapping and text format as everywhere (pop_factory.py:471-513, rowgen_kernels.hip.h).
-// Used for rows of fewer than 150 groups (S < 600): 0.23 instead of 0.13 of the HBM peak at S = 100, 0.30 / 0.21 at 200,
-// 0.33 / 0.30 at 400; from 600 samples on a wave per row segment is as fast (profiles/r02_shapes.txt).  The kernel is bound
-// by its instruction count here too: the per-lane bookkeeping (row and group of a lane, addresses, the fixed columns)
-// is 50 instructions on top of the 90 of the Philox group.
+// Used for rows of fewer than 420 groups (S < 1,680): 0.30 instead of 0.13 of the HBM peak at S = 100, 0.38 / 0.21 at 200,
+// 0.46 / 0.30 at 400, 0.49 / 0.43 at 1,000; from there on a wave per run of whole rows is as fast (profiles/r02_shapes.txt).
+// The per-lane bookkeeping (row and group of a lane, addresses, the fixed columns) is 50 instructions on top of the 90 of
+// the Philox group; a wave's start-up (its rows' records, then the row table) is a tenth of its life.
 #pragma once
 #include "rowrun_kernels.hip.h"
 
@@ -37,13 +37,46 @@ __device__ __forceinline__ void divmod_small(uint32_t q, uint32_t d, uint32_t m,
     rem = g;
 }
 
-constexpr uint32_t MIX_PFX_BYTES = 3072; // the fixed columns of a run's rows, cached in LDS (64 rows x 48 bytes)
+#ifndef DNAF_MIX_PFX_BYTES
+#define DNAF_MIX_PFX_BYTES 4096
+#endif
+#ifndef DNAF_MIX_BOUNDS
+#define DNAF_MIX_BOUNDS __launch_bounds__(256)
+#endif
+#ifndef DNAF_MIX_EXP
+#define DNAF_MIX_EXP 0
+#endif
+constexpr uint32_t MIX_PFX_BYTES = DNAF_MIX_PFX_BYTES; // the fixed columns of a run's rows, cached in LDS (64 rows x 64 bytes)
+constexpr uint32_t MIX_MAX_GROUPS = 500; // the host never sends longer rows here
+constexpr uint32_t MIX_STAGE = 512;      // packed bytes of one row handled a row at a time (MIX_MAX_GROUPS + pad)
+
+// prefix_fixed[j] = the fixed columns of row j, zero-padded to `stride` bytes (a multiple of 16): one thread per row
+__global__ __launch_bounds__(256) void prefix_fix_kernel(const RowRec* recs, const uint8_t* prefix, uint8_t* out, uint64_t n, uint32_t stride)
+{
+    const uint64_t j = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    if (j >= n) return;
+    const uint8_t* src = prefix + recs[j].prefix_off;
+    const uint32_t len = recs[j].prefix_len;
+    uint8_t* dst = out + j * stride;
+    for (uint32_t i = 0; i < stride; ++i) dst[i] = i < len ? src[i] : (uint8_t)0;
+}
+
+#ifdef DNAF_MIX_PROFILE
+// stage clock of rowmix_kernel: cycles (s_memtime) summed over waves; debug builds only (tools/mix_stage_profile.py)
+__device__ unsigned long long mix_prof[16];
+#define MIX_STAMP(k) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); if (lane_id == 0) atomicAdd(&mix_prof[k], t_ - t_prev_); t_prev_ = t_; } while (0)
+#else
+#define MIX_STAMP(k) do { } while (0)
+#endif
 
 template <bool TEXT, bool PACKED>
-__global__ __launch_bounds__(256) void rowmix_kernel(const GenParams p)
+__global__ DNAF_MIX_BOUNDS void rowmix_kernel(const GenParams p)
 {
+#ifdef DNAF_MIX_PROFILE
+    unsigned long long t_prev_ = __builtin_amdgcn_s_memtime();
+#endif
     __shared__ u32x4_t cell_lut[256];
-    __shared__ __attribute__((aligned(16))) uint8_t pk_stage[4][PK_STAGE];
+    __shared__ __attribute__((aligned(16))) uint8_t pk_stage[4][MIX_STAGE];
     __shared__ __attribute__((aligned(16))) MixRow rows_all[4][64];
     __shared__ __attribute__((aligned(16))) uint8_t pfx_all[4][MIX_PFX_BYTES];
     if (TEXT) {
@@ -54,6 +87,7 @@ __global__ __launch_bounds__(256) void rowmix_kernel(const GenParams p)
         __syncthreads();
     }
     const uint32_t lane_id = threadIdx.x & 63u;
+    MIX_STAMP(0); // cell table + barrier
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint64_t run = (uint64_t)blockIdx.x * 4u + wave;
     const uint32_t R = p.rows_per_wave; // <= 64
@@ -74,6 +108,19 @@ __global__ __launch_bounds__(256) void rowmix_kernel(const GenParams p)
     uint8_t* packed_run = p.packed + j0 * p.packed_pitch;
     const uint32_t pitch32 = (uint32_t)p.packed_pitch;
     RowRec myrec = p.recs[p.row_begin + j0 + (lane_id < nrun ? lane_id : 0u)];
+    // The fixed columns of the run's rows go into LDS once, so that no trip waits on a global load for the few dozen bytes in
+    // front of a row (that wait, once per row, was what bound the kernel at 200 samples).  Where they are in the prefix blob
+    // is written in the rows' records -- a load that depends on a load, and a wave's life is short (a third of it was the
+    // start-up, tools/mix_stage_profile.py) -- so the library keeps a second copy of them at a fixed stride (prefix_fixed):
+    // lane = row asks for its row's bytes together with its record.  Without that copy: the run's piece of the blob, below.
+    const uint32_t pstride = p.prefix_stride;
+    u32x4_t pv[4] = {u32x4_t{0, 0, 0, 0}, u32x4_t{0, 0, 0, 0}, u32x4_t{0, 0, 0, 0}, u32x4_t{0, 0, 0, 0}};
+    if (TEXT && pstride) { // wave-uniform
+        const uint8_t* src = p.prefix_fixed + (p.row_begin + j0 + (lane_id < nrun ? lane_id : 0u)) * pstride;
+#pragma unroll
+        for (uint32_t k = 0; k < 4u; ++k)
+            if (16u * k < pstride) pv[k] = *reinterpret_cast<const u32x4_t*>(src + 16u * k);
+    }
     const bool ordinary = lane_id < nrun && myrec.cls == 0u && myrec.n_alleles == 2 && myrec.slot < 0;
     const uint32_t my_rel = (uint32_t)(myrec.text_off - text0), my_plen = myrec.prefix_len, my_poff = myrec.prefix_off;
     {
@@ -90,16 +137,24 @@ __global__ __launch_bounds__(256) void rowmix_kernel(const GenParams p)
             *reinterpret_cast<LDS_PTR(u32x4_t)>(&tab[lane_id].t0) = u32x4_t{e.t0, e.cells_rel, 0u, 0u};
         }
     }
+    MIX_STAMP(1); // records loaded, row table written
     const uint64_t ord_mask = __ballot(ordinary);
-    // The fixed columns of the run's rows are one contiguous piece of the prefix blob: into LDS with one round of loads, so
-    // that no trip waits on a global load for the few dozen bytes in front of a row (that wait, once per row, was what
-    // bound the kernel at 200 samples).
     const uint32_t pfx0 = __builtin_amdgcn_readlane(my_poff, 0);
     const uint32_t pfx_bytes = __builtin_amdgcn_readlane(my_poff + my_plen, nrun - 1u) - pfx0;
-    const bool pfx_cached = TEXT && pfx_bytes <= MIX_PFX_BYTES;
+    const bool pfx_cached = TEXT && (pstride != 0u || pfx_bytes <= MIX_PFX_BYTES) && DNAF_MIX_EXP != 1;
     LDS_PTR(uint8_t) pfx = (LDS_PTR(uint8_t))pfx_all[threadIdx.x >> 6];
-    if (pfx_cached)
+    if (TEXT && pstride) {
+        if (lane_id < nrun) {
+#pragma unroll
+            for (uint32_t k = 0; k < 4u; ++k)
+                if (16u * k < pstride) *reinterpret_cast<LDS_PTR(u32x4_t)>(pfx + lane_id * pstride + 16u * k) = pv[k];
+        }
+    } else if (pfx_cached)
         for (uint32_t i = lane_id; i < pfx_bytes; i += 64u) pfx[i] = p.prefix[pfx0 + i];
+#ifdef DNAF_MIX_PROFILE
+    if (pfx_cached) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#endif
+    MIX_STAMP(2); // fixed columns in LDS
     const RowKeys keys = make_row_keys(p.key0, p.key1);
     const uint32_t gmagic = (uint32_t)min(0x100000000ull / G, 0xFFFFFFFFull);
     const uint32_t nvalid_last = S - 4u * (G - 1u); // samples in a row's last group, 1 .. 4
@@ -139,6 +194,21 @@ __global__ __launch_bounds__(256) void rowmix_kernel(const GenParams p)
             divmod_small(live ? q : 0u, G, gmagic, row, g);
             row += r;
         };
+        if (TEXT && !pfx_cached) {
+            // no copy of the fixed columns in LDS (they are longer than the cache): all of the stretch's, ahead of its trips.
+            // Kept out of the trip loop: a global load in there makes the compiler wait for the loop's STORES too (vmcnt
+            // counts both), once per trip.
+            for (uint32_t rr = r; rr < e; ++rr) {
+                const uint32_t plen = __builtin_amdgcn_readlane(my_plen, rr), poff = __builtin_amdgcn_readlane(my_poff, rr);
+                const uint32_t rel = __builtin_amdgcn_readlane(my_rel, rr);
+                for (uint32_t i = lane; i < plen; i += 64) run_text[rel + i] = p.prefix[poff + i];
+            }
+        }
+        // No load is in flight past this point.  The waves' loads above and in the other branch of this loop would otherwise
+        // leave the compiler's scoreboard with "maybe pending" registers at the head of the trip loop, and it would wait for
+        // vmcnt inside the loop -- where that counter also holds the loop's own stores, i.e. every trip would wait for the
+        // stores of the trip before it (measured: the vector units 67 % busy).  vmcnt(0), other counters untouched.
+        __builtin_amdgcn_s_waitcnt(0x0F70);
         uint32_t row0, g0;
         bool live0;
         coords(0u, row0, g0, live0);
@@ -171,14 +241,13 @@ __global__ __launch_bounds__(256) void rowmix_kernel(const GenParams p)
                 xs1 = *reinterpret_cast<const LDS_PTR(u32x4_t)>(&tab[row1]);
                 ts1 = *reinterpret_cast<const LDS_PTR(u32x4_t)>(&tab[row1].t0);
             }
-            if (TEXT) {
+            if (TEXT && pfx_cached) {
                 // fixed columns of the rows that begin in this trip (pop_factory.py:503-507, formatted on the host)
-                while (next_row < e && next_q < qb + 64u) {
+                while (DNAF_MIX_EXP == 0 && next_row < e && next_q < qb + 64u) {
                     const uint32_t plen = __builtin_amdgcn_readlane(my_plen, next_row);
-                    const uint32_t poff = __builtin_amdgcn_readlane(my_poff, next_row);
                     const uint32_t rel = __builtin_amdgcn_readlane(my_rel, next_row);
-                    if (pfx_cached) { for (uint32_t i = lane; i < plen; i += 64) run_text[rel + i] = pfx[poff - pfx0 + i]; }
-                    else { for (uint32_t i = lane; i < plen; i += 64) run_text[rel + i] = p.prefix[poff + i]; }
+                    const uint32_t at = pstride ? next_row * pstride : __builtin_amdgcn_readlane(my_poff, next_row) - pfx0;
+                    for (uint32_t i = lane; i < plen; i += 64) run_text[rel + i] = pfx[at + i];
                     ++next_row;
                     next_q += G;
                 }
@@ -210,6 +279,12 @@ __global__ __launch_bounds__(256) void rowmix_kernel(const GenParams p)
         }
         r = e;
     }
+    MIX_STAMP(3); // the rows
+#ifdef DNAF_MIX_PROFILE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    MIX_STAMP(4); // stores drained
+    if (lane_id == 0) atomicAdd(&mix_prof[8], 1ull);
+#endif
 }
 
 } // namespace dnaf
