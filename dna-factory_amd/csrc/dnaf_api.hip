@@ -812,9 +812,15 @@ int dnaf_generate(dnaf_ctx* c, uint64_t row_begin, uint64_t n_rows, uint32_t wha
     if (rec) HIP_TRY(c, hipEventRecord(c->evs[2 * c->n_timed], c->stream));
     const dim3 grid((uint32_t)blocks), block(256);
     if (use_mix) {
-        if (what == (DNAF_OUT_TEXT | DNAF_OUT_PACKED)) hipLaunchKernelGGL((dnaf::rowmix_kernel<true, true>), grid, block, 0, c->stream, p);
-        else if (what == DNAF_OUT_TEXT) hipLaunchKernelGGL((dnaf::rowmix_kernel<true, false>), grid, block, 0, c->stream, p);
-        else hipLaunchKernelGGL((dnaf::rowmix_kernel<false, true>), grid, block, 0, c->stream, p);
+        const bool full4 = c->S % 4u == 0u;
+        if (what == (DNAF_OUT_TEXT | DNAF_OUT_PACKED)) {
+            if (full4) hipLaunchKernelGGL((dnaf::rowmix_kernel<true, true, true>), grid, block, 0, c->stream, p);
+            else hipLaunchKernelGGL((dnaf::rowmix_kernel<true, true, false>), grid, block, 0, c->stream, p);
+        } else if (what == DNAF_OUT_TEXT) {
+            if (full4) hipLaunchKernelGGL((dnaf::rowmix_kernel<true, false, true>), grid, block, 0, c->stream, p);
+            else hipLaunchKernelGGL((dnaf::rowmix_kernel<true, false, false>), grid, block, 0, c->stream, p);
+        } else if (full4) hipLaunchKernelGGL((dnaf::rowmix_kernel<false, true, true>), grid, block, 0, c->stream, p);
+        else hipLaunchKernelGGL((dnaf::rowmix_kernel<false, true, false>), grid, block, 0, c->stream, p);
     } else if (use_runs) {
         // the cap on workgroups per CU pays for long rows (a wave's passes get closer in time); waves that walk several
         // short rows have more per-row latency to cover and want the full occupancy (S = 4,000: 0.61 without, 0.57 with)

@@ -69,7 +69,8 @@ __device__ unsigned long long mix_prof[16];
 #define MIX_STAMP(k) do { } while (0)
 #endif
 
-template <bool TEXT, bool PACKED>
+// FULL4: the sample count is a multiple of 4 (every group whole): the row's last group needs only its newline
+template <bool TEXT, bool PACKED, bool FULL4>
 __global__ DNAF_MIX_BOUNDS void rowmix_kernel(const GenParams p)
 {
 #ifdef DNAF_MIX_PROFILE
@@ -157,7 +158,8 @@ __global__ DNAF_MIX_BOUNDS void rowmix_kernel(const GenParams p)
     MIX_STAMP(2); // fixed columns in LDS
     const RowKeys keys = make_row_keys(p.key0, p.key1);
     const uint32_t gmagic = (uint32_t)min(0x100000000ull / G, 0xFFFFFFFFull);
-    const uint32_t nvalid_last = S - 4u * (G - 1u); // samples in a row's last group, 1 .. 4
+    const uint32_t nvalid_last = FULL4 ? 4u : S - 4u * (G - 1u); // samples in a row's last group, 1 .. 4
+    const uint32_t step_rows = 64u / G, step_groups = 64u - step_rows * G; // a trip ahead: 64 groups = step_rows rows + step_groups
     const uint32_t fix = 0x0A000000u - 0x09000000u; // '\n' instead of the last '\t'
 
     uint32_t r = 0;
@@ -191,7 +193,7 @@ __global__ DNAF_MIX_BOUNDS void rowmix_kernel(const GenParams p)
         auto coords = [&](uint32_t qb, uint32_t& row, uint32_t& g, bool& live) {
             const uint32_t q = qb + lane;
             live = q < n;
-            divmod_small(live ? q : 0u, G, gmagic, row, g);
+            divmod_small(q, G, gmagic, row, g); // lanes past the stretch get coordinates too: they are stepped from there
             row += r;
         };
         if (TEXT && !pfx_cached) {
@@ -220,7 +222,7 @@ __global__ DNAF_MIX_BOUNDS void rowmix_kernel(const GenParams p)
         auto store_prev = [&]() {
             if (!live_prev) return;
             uint8_t* dst = run_text + off_prev;
-            if (nvalid_last == 4u) { // wave-uniform: every group is whole, the row's last one ends in a newline
+            if (FULL4) { // every group is whole, the row's last one ends in a newline
                 w_prev.w += last_prev ? fix : 0u;
                 store_unaligned<16>(dst, &w_prev);
             } else if (!last_prev) store_unaligned<16>(dst, &w_prev);
@@ -237,7 +239,12 @@ __global__ DNAF_MIX_BOUNDS void rowmix_kernel(const GenParams p)
             bool live1 = false;
             u32x4_t xs1 = xs0, ts1 = ts0;
             if (qb + 64u < n) { // wave-uniform
-                coords(qb + 64u, row1, g1, live1);
+                // one trip on: no division, the lane's group moves by 64 mod G and its row by 64 / G (+ 1 when the group wraps)
+                const uint32_t gs = g0 + step_groups;
+                const bool wrap = gs >= G;
+                g1 = wrap ? gs - G : gs;
+                row1 = row0 + step_rows + (wrap ? 1u : 0u);
+                live1 = qb + 64u + lane < n;
                 xs1 = *reinterpret_cast<const LDS_PTR(u32x4_t)>(&tab[row1]);
                 ts1 = *reinterpret_cast<const LDS_PTR(u32x4_t)>(&tab[row1].t0);
             }
