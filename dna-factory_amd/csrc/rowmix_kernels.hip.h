@@ -234,10 +234,10 @@ __global__ DNAF_MIX_BOUNDS void rowmix_kernel(const GenParams p)
                 if (nvalid_last > 2u) store_unaligned<4>(dst + 8, &w2);
             }
         };
-        for (uint32_t qb = 0; qb < n; qb += 64u) {
-            uint32_t row1 = row0, g1 = g0;
-            bool live1 = false;
-            u32x4_t xs1 = xs0, ts1 = ts0;
+        // one trip at qb with the current coordinates / table entries (row0, g0, live0, xs0, ts0); those of the trip after it
+        // are produced into (row1, ...).  Called alternately with the two register sets, so nothing is copied between trips.
+        auto trip = [&](uint32_t qb, uint32_t row0, uint32_t g0, bool live0, const u32x4_t& xs0, const u32x4_t& ts0, uint32_t& row1,
+                        uint32_t& g1, bool& live1, u32x4_t& xs1, u32x4_t& ts1) {
             if (qb + 64u < n) { // wave-uniform
                 // one trip on: no division, the lane's group moves by 64 mod G and its row by 64 / G (+ 1 when the group wraps)
                 const uint32_t gs = g0 + step_groups;
@@ -274,7 +274,15 @@ __global__ DNAF_MIX_BOUNDS void rowmix_kernel(const GenParams p)
                 if (last) pk &= (1u << (2u * nvalid_last)) - 1u; // codes of samples past the end stay 0
                 packed_run[row0 * pitch32 + g0] = (uint8_t)pk;   // 32-bit offsets from the run's first packed byte
             }
-            row0 = row1; g0 = g1; live0 = live1; xs0 = xs1; ts0 = ts1;
+        };
+        {
+            uint32_t row1 = row0, g1 = g0;
+            bool live1 = false;
+            u32x4_t xs1 = xs0, ts1 = ts0;
+            for (uint32_t qb = 0; qb < n; qb += 128u) {
+                trip(qb, row0, g0, live0, xs0, ts0, row1, g1, live1, xs1, ts1);
+                if (qb + 64u < n) trip(qb + 64u, row1, g1, live1, xs1, ts1, row0, g0, live0, xs0, ts0);
+            }
         }
         if (TEXT && have_prev) store_prev();
         if (PACKED && g_stop > G) { // pad bytes of the stretch's packed rows (at most 3 per row)
