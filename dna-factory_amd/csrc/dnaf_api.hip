@@ -138,7 +138,7 @@ struct dnaf_ctx {
     uint64_t min_run_waves = 8192;   // fewer runs than this and long rows: the segment form fills the GPU better
     uint32_t force_rpw = 0;          // DNAF_ROWS_PER_WAVE: rows per wave of the line-owning form (tests)
     bool no_rowmix = false;          // DNAF_NO_ROWMIX=1: never the short-row form (A/B runs)
-    uint32_t mix_max_groups = 420;   // rows of fewer groups than this (S < 1,680) take the short-row form (measured crossover)
+    uint32_t mix_max_groups = 509;   // rows of fewer groups than this take the short-row form: every shape with a dense packed pitch
     uint32_t run_lds_pad = DNAF_RUN_LDS_PAD_DEFAULT; // unused dynamic LDS per workgroup of rowrun_kernel: caps the workgroups per CU
 };
 

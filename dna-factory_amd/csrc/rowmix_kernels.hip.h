@@ -13,10 +13,11 @@
 // code of rowrun_kernels.hip.h in between.
 //
 // Same cell rules, RNG lane mapping and text format as everywhere (pop_factory.py:471-513, rowgen_kernels.hip.h).
-// Used for rows of fewer than 420 groups (S < 1,680): 0.30 instead of 0.13 of the HBM peak at S = 100, 0.38 / 0.21 at 200,
-// 0.46 / 0.30 at 400, 0.49 / 0.43 at 1,000; from there on a wave per run of whole rows is as fast (profiles/r02_shapes.txt).
-// The per-lane bookkeeping (row and group of a lane, addresses, the fixed columns) is 50 instructions on top of the 90 of
-// the Philox group; a wave's start-up (its rows' records, then the row table) is a tenth of its life.
+// Used wherever the packed rows are dense (W < 128 words, S <= 2,032): 0.32 instead of 0.13 of the HBM peak at S = 100,
+// 0.40 / 0.21 at 200, 0.48 / 0.30 at 400, 0.50 / 0.43 at 1,000, 0.555 / 0.52 at 2,000 (profiles/r02_shapes.txt; second
+// figure: a wave per row segment, from 1,021 samples a wave per run of whole rows).  The per-lane bookkeeping (row and
+// group of a lane, addresses, the fixed columns) is 30 instructions on top of the 90 of the Philox group; a wave's
+// start-up (its rows' records, then the row table) is a tenth of its life.
 #pragma once
 #include "rowrun_kernels.hip.h"
 
@@ -47,8 +48,8 @@ __device__ __forceinline__ void divmod_small(uint32_t q, uint32_t d, uint32_t m,
 #define DNAF_MIX_EXP 0
 #endif
 constexpr uint32_t MIX_PFX_BYTES = DNAF_MIX_PFX_BYTES; // the fixed columns of a run's rows, cached in LDS (64 rows x 64 bytes)
-constexpr uint32_t MIX_MAX_GROUPS = 500; // the host never sends longer rows here
-constexpr uint32_t MIX_STAGE = 512;      // packed bytes of one row handled a row at a time (MIX_MAX_GROUPS + pad)
+constexpr uint32_t MIX_MAX_GROUPS = 509; // the host never sends rows of this many groups or more here (dense pitch: S <= 2,032)
+constexpr uint32_t MIX_STAGE = 768;      // packed bytes of one row handled a row at a time (< MIX_MAX_GROUPS + pad)
 
 // prefix_fixed[j] = the fixed columns of row j, zero-padded to `stride` bytes (a multiple of 16): one thread per row
 __global__ __launch_bounds__(256) void prefix_fix_kernel(const RowRec* recs, const uint8_t* prefix, uint8_t* out, uint64_t n, uint32_t stride)
