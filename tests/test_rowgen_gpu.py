@@ -318,6 +318,31 @@ def test_short_row_kernel_fuzz(RowGenerator, oracle, monkeypatch, rpw):
         check_case(RowGenerator, oracle, snps, samples, seed=int(rs.randint(0, 2**31)), rng_row0=int(rs.randint(0, 1000)))
 
 
+@pytest.mark.parametrize("share_long", [0.1, 1.0])
+def test_short_rows_with_long_fixed_columns(RowGenerator, oracle, share_long):
+    """Rows whose fixed columns are longer than 64 bytes (15-letter alleles -- the oracle's records hold no longer ones -- and
+    13-digit ids): the library then keeps no fixed-stride copy
+    of them (rowmix_kernel falls back to the run's piece of the prefix blob in LDS), and when a run's fixed columns exceed
+    that cache too (every row long) they are copied from global memory ahead of the trips."""
+    rs = np.random.RandomState(int(1000 * share_long) + 77)
+    snps, samples = random_case(rs, 260, 120, p_sex_chrom=0.1, n_del=2)
+    long_a, long_b = "ACGTACGTACGTACG", "TTGCATTGCATTGCA"
+    snps = [(i + 10**12, ch, pos, [(long_a if k == 0 else long_b if k == 1 else a, c) for k, (a, c) in enumerate(tu)])
+            if rs.rand() < share_long else (i, ch, pos, tu) for (i, ch, pos, tu) in snps]
+    samples = [(sex, ctrl, None if car is None else [c + 10**12 if any(c + 10**12 == sn[0] for sn in snps) else c for c in car])
+               for (sex, ctrl, car) in samples]
+    check_case(RowGenerator, oracle, snps, samples, seed=int(rs.randint(0, 2**31)))
+
+
+@pytest.mark.parametrize("S", [2029, 2032, 2033, 2036])
+def test_shapes_around_the_dense_pitch_limit(RowGenerator, oracle, S):
+    """2,032 samples = 127 packed words per row is the last dense pitch (short-row form); from 2,033 on the rows are padded
+    to 128-byte lines (line-owning form)."""
+    rs = np.random.RandomState(S)
+    snps, samples = random_case(rs, 150, S, p_sex_chrom=0.2)
+    check_case(RowGenerator, oracle, snps, samples, seed=int(rs.randint(0, 2**31)), rng_row0=5)
+
+
 def test_short_row_and_segment_forms_write_the_same_bytes(RowGenerator, oracle, monkeypatch):
     rs = np.random.RandomState(6060)
     snps, samples = random_case(rs, 700, 200, p_sex_chrom=0.2)
