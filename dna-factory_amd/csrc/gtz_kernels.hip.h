@@ -95,7 +95,8 @@ struct GtzShared {
     uint32_t far[GTZ_MAX_CHUNKS * GTZ_MAX_FAR]; // cell in chunk | cells << 6 | distance in bytes << 13
     uint32_t codes[256 + 256 + 32];             // lit, len, dist code tables; the symbol histogram in gtz_encode<true>
     uint32_t crc_table[256];
-    uint32_t crc_base[GTZ_CHUNK_CELLS + 1], crc_unit_a[GTZ_CHUNK_CELLS], crc_unit_b[GTZ_CHUNK_CELLS];
+    uint32_t crc_base[GTZ_CHUNK_CELLS + 1];
+    uint32_t crc_unit_a[2 * GTZ_CHUNK_CELLS]; // first allele's units, then (crc_unit_b) the second allele's
     // rows overlapping the member
     int32_t off[GTZ_MAX_ROWS + 2];     // row start relative to the member's first byte
     int32_t cs[GTZ_MAX_ROWS + 2];      // first cell's byte, relative to the member
@@ -388,7 +389,7 @@ __global__ __launch_bounds__(GTZ_THREADS) void gtz_encode(const GtzParams p)
         if (tid < 32) s->dist()[tid] = ct->dist[tid];
         s->crc_table[tid] = p.tables->crc_table[tid];
         if (tid <= GTZ_CHUNK_CELLS) s->crc_base[tid] = p.tables->crc_base[tid];
-        if (tid < GTZ_CHUNK_CELLS) { s->crc_unit_a[tid] = p.tables->crc_unit_a[tid]; s->crc_unit_b[tid] = p.tables->crc_unit_b[tid]; }
+        if (tid < GTZ_CHUNK_CELLS) { s->crc_unit_a[tid] = p.tables->crc_unit_a[tid]; s->crc_unit_a[GTZ_CHUNK_CELLS + tid] = p.tables->crc_unit_b[tid]; }
     }
     __syncthreads();
     GTZ_STAMP(1); // cells and code tables in LDS
@@ -481,15 +482,26 @@ __global__ __launch_bounds__(GTZ_THREADS) void gtz_encode(const GtzParams p)
                 GtzSymbolCount hs{s->hist()};
                 gtz_emit_tokens(ch[u], tk, farlist, hs);
             } else {
-                GtzBitCount cnt{lit_bits, {ct->len_nb[0], ct->len_nb[1]}, {ct->dist_nb[0], ct->dist_nb[1]}, 0};
+                GtzBitCount cnt{lit_bits, s->len(), s->dist(), 0};
                 bits[u] = gtz_count_bits(ch[u], tk, farlist, cnt);
-                // CRC of the chunk's bytes from its cells: base pattern + one unit per '1'
+                // CRC of the chunk's bytes from its cells: base pattern + one unit per '1' allele.  Only the set bits of the
+                // chunk's code words are visited (a tenth to a third of the 128 alleles), not every cell.
                 const uint32_t n = k1 - k0;
                 uint32_t cc = s->crc_base[n];
-                for (uint32_t e = 0; e < n; ++e) {
-                    const uint32_t code = ch[u].code(ch[u].j1 - 1u - e);
-                    cc ^= (code & 1u) ? s->crc_unit_a[e] : 0u;
-                    cc ^= (code & 2u) ? s->crc_unit_b[e] : 0u;
+                {
+                    const uint32_t a = 2u * ch[u].j0, b = 2u * ch[u].j1;
+                    uint64_t wlo = ch[u].lo & gtz_low_mask(min(b, 64u)) & ~gtz_low_mask(min(a, 64u));
+                    uint64_t whi = ch[u].hi & gtz_low_mask(b > 64u ? b - 64u : 0u) & ~gtz_low_mask(a > 64u ? a - 64u : 0u);
+                    const uint32_t* unit = s->crc_unit_a; // crc_unit_b follows it: [allele][cells before the end]
+                    const uint32_t last = ch[u].j1 - 1u;
+                    while (wlo | whi) {
+                        const bool low = wlo != 0;
+                        const uint64_t w = low ? wlo : whi;
+                        const uint32_t bit = (uint32_t)__builtin_ctzll(w);
+                        if (low) wlo &= wlo - 1; else whi &= whi - 1;
+                        const uint32_t j = (low ? 0u : 32u) + (bit >> 1);
+                        cc ^= unit[(bit & 1u) * GTZ_CHUNK_CELLS + (last - j)];
+                    }
                 }
                 crc = cc;
                 nbytes = 4u * n;

@@ -78,20 +78,18 @@ __device__ __forceinline__ GtzTokens gtz_tokens(const GtzChunk& c, const uint32_
 
 // Sinks receive literals as a kind (0 '0', 1 '1', 2 '/', 3 '\t') and matches as (length, distance in bytes).
 struct GtzBitCount {
-    uint32_t lit_bits;   // 4 x 8 bits: code length of each literal kind
-    uint64_t len_nb[2];  // 29 nibbles: code length of length symbol 257 + n
-    uint64_t dist_nb[2]; // 30 nibbles: code length of distance symbol n
+    uint32_t lit_bits;     // 4 x 8 bits: code length of each literal kind
+    const uint32_t* len;   // LDS: match length -> code + extra bits, total bit count in the low 5 bits
+    const uint32_t* dist;  // LDS: distance symbol -> code, its length in the low 5 bits
     uint32_t bits;
     __device__ __forceinline__ void lit(uint32_t kind) { bits += (lit_bits >> (8u * kind)) & 0xFFu; }
+    // one table read per match (the distance symbol of the distance-4 matches folds to a constant at the call site);
+    // working the length symbol out in registers instead cost 20 instructions per match
     __device__ __forceinline__ void match(uint32_t L, uint32_t d)
     {
-        const uint32_t ls = gtz_len_symbol(L) - 257u;
         uint32_t sym, eb, ev;
         gtz_dist_symbol(d, &sym, &eb, &ev);
-        const uint32_t lb = (uint32_t)(len_nb[ls >> 4] >> (4u * (ls & 15u))) & 15u;
-        const uint32_t db = (uint32_t)(dist_nb[sym >> 4] >> (4u * (sym & 15u))) & 15u;
-        const uint32_t leb = (ls < 8u || ls == 28u) ? 0u : (ls - 4u) >> 2;
-        bits += lb + leb + db + eb;
+        bits += (len[L - 3u] & 31u) + (dist[sym] & 31u) + eb;
     }
 };
 

@@ -1,12 +1,12 @@
 #!/bin/bash
-# vector-instruction counts of the row kernels at the short shapes (S = 200: rowmix_kernel, S = 2000: rowrun_kernel)
+# vector-instruction counts of the row kernels at other shapes; usage: tools/run_prof_shapes.sh [S ...]  (default 200 2000)
 set -e -o pipefail
 cd "$GRAFT_REPO_ROOT"
 export TMPDIR=/tmp
 O=gpurun_out/profshapes
 mkdir -p $O
-for S in 200 2000; do
-  T=$([ $S = 200 ] && echo 5000000 || echo 2500000)
+for S in ${@:-200 2000}; do
+  T=$(( 1000000000 / (S * 2) )); [ $T -gt 5000000 ] && T=5000000
   rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_LDS SQ_WAVES -d $O/S$S -o pmc -f csv -- python3 bench.py --cpu-seconds 0 --bgzf-tiles 0 --samples $S --tile-rows $T --table-rows 5000000 --steps 3 --warmup 2 > $O/S$S.log 2>&1
   python - $S $T <<'PY'
 import csv, collections, sys
