@@ -284,6 +284,9 @@ __device__ unsigned long long gtz_prof[16];
 #define GTZ_STAMP(k) do { } while (0)
 #endif
 
+#ifndef DNAF_GTZ_EXP
+#define DNAF_GTZ_EXP 0 // timing experiments (output invalid): 1 no search, 2 no emission walk, 3 no count walk, 4 no key tables, 5 no CRC
+#endif
 template <bool HIST>
 __global__ __launch_bounds__(GTZ_THREADS) void gtz_encode(const GtzParams p)
 {
@@ -398,7 +401,7 @@ __global__ __launch_bounds__(GTZ_THREADS) void gtz_encode(const GtzParams p)
     // that stay are 16 KB instead of 32, which is what lets a fourth workgroup share the CU.
     {
         uint32_t* scr = s->far; // [0, KEYS): earliest, [KEYS, 2 KEYS): latest + 1
-        for (uint32_t q = 0; q < GTZ_SEGS; ++q) {
+        for (uint32_t q = 0; q < (DNAF_GTZ_EXP == 4 ? 0u : GTZ_SEGS); ++q) {
             for (uint32_t t = tid; t < 2 * GTZ_KEYS; t += GTZ_THREADS) scr[t] = t < GTZ_KEYS ? 0xFFFFFFFFu : 0u;
             __syncthreads();
             const uint32_t qlo = q << GTZ_SEG_SHIFT, qhi = q + 1u == GTZ_SEGS ? 0xFFFFFFFFu : (q + 1u) << GTZ_SEG_SHIFT;
@@ -475,7 +478,7 @@ __global__ __launch_bounds__(GTZ_THREADS) void gtz_encode(const GtzParams p)
             uint32_t* farlist = s->far + (s->chunk_base[i] + local - 1u) * GTZ_MAX_FAR;
             it_far[u] = farlist;
             ch[u] = gtz_load_chunk(s, i, c64, k0, k1);
-            gtz_find_matches(s, i, c64, ch[u], farlist);
+            if (DNAF_GTZ_EXP == 1) farlist[0] = 0; else gtz_find_matches(s, i, c64, ch[u], farlist);
             tks[u] = gtz_tokens(ch[u], farlist);
             const GtzTokens& tk = tks[u];
             if (HIST) {
@@ -483,7 +486,7 @@ __global__ __launch_bounds__(GTZ_THREADS) void gtz_encode(const GtzParams p)
                 gtz_emit_tokens(ch[u], tk, farlist, hs);
             } else {
                 GtzBitCount cnt{lit_bits, s->len(), s->dist(), 0};
-                bits[u] = gtz_count_bits(ch[u], tk, farlist, cnt);
+                bits[u] = DNAF_GTZ_EXP == 3 ? 150u : gtz_count_bits(ch[u], tk, farlist, cnt);
                 // CRC of the chunk's bytes from its cells: base pattern + one unit per '1' allele.  Only the set bits of the
                 // chunk's code words are visited (a tenth to a third of the 128 alleles), not every cell.
                 const uint32_t n = k1 - k0;
@@ -494,7 +497,7 @@ __global__ __launch_bounds__(GTZ_THREADS) void gtz_encode(const GtzParams p)
                     uint64_t whi = ch[u].hi & gtz_low_mask(b > 64u ? b - 64u : 0u) & ~gtz_low_mask(a > 64u ? a - 64u : 0u);
                     const uint32_t* unit = s->crc_unit_a; // crc_unit_b follows it: [allele][cells before the end]
                     const uint32_t last = ch[u].j1 - 1u;
-                    while (wlo | whi) {
+                    while (DNAF_GTZ_EXP != 5 && (wlo | whi)) {
                         const bool low = wlo != 0;
                         const uint64_t w = low ? wlo : whi;
                         const uint32_t bit = (uint32_t)__builtin_ctzll(w);
@@ -589,7 +592,7 @@ __global__ __launch_bounds__(GTZ_THREADS) void gtz_encode(const GtzParams p)
             e.flush();
         } else {
             GtzBitEmit e{s->image, s->len(), s->dist(), {s->lit()['0'], s->lit()['1'], s->lit()['/'], s->lit()['\t']}, 0, start & 31u, start >> 5};
-            gtz_emit_tokens(ch[u], tks[u], it_far[u], e);
+            if (DNAF_GTZ_EXP != 2) gtz_emit_tokens(ch[u], tks[u], it_far[u], e);
             e.flush();
         }
     }

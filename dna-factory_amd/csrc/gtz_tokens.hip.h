@@ -34,6 +34,7 @@ __device__ __forceinline__ uint64_t gtz_range_word(uint32_t lo, uint32_t hi, uin
 // covered by an LZ77 match); far: first byte of each recorded LZ77 match.
 struct GtzTokens {
     uint64_t run3[4], plain[4], far[4];
+    uint32_t ext[4]; // ext[w]: bytes by which a distance-4 run that reaches the end of word w goes on in the words after it
 };
 
 __device__ __forceinline__ GtzTokens gtz_tokens(const GtzChunk& c, const uint32_t* farlist)
@@ -72,6 +73,13 @@ __device__ __forceinline__ GtzTokens gtz_tokens(const GtzChunk& c, const uint32_
         const uint64_t up = (M[w] << 1) | (below >> 63), up2 = (M[w] << 2) | (below >> 62);
         const uint64_t dn = (M[w] >> 1) | (above << 63), dn2 = (M[w] >> 2) | (above << 62);
         t.run3[w] = M[w] & ((up & up2) | (up & dn) | (dn & dn2));
+    }
+    // worked out once here, not at every match of the two token walks
+    t.ext[3] = 0;
+#pragma unroll
+    for (int w = 2; w >= 0; --w) {
+        const uint32_t more = ~t.run3[w + 1] ? (uint32_t)__builtin_ctzll(~t.run3[w + 1]) : 64u;
+        t.ext[w] = more + (more == 64u ? t.ext[w + 1] : 0u);
     }
     return t;
 }
@@ -173,18 +181,8 @@ __device__ __forceinline__ uint32_t gtz_count_bits(const GtzChunk& c, const GtzT
                 const uint32_t e = farlist[nfar++];
                 cnt.match(4u * ((e >> 6) & 127u), e >> 13);
             } else {
-                uint32_t L;
-                const uint64_t stop = ~r & ~gtz_low_mask(p);
-                if (stop) L = (uint32_t)__builtin_ctzll(stop) - p;
-                else {
-                    L = 64u - p;
-#pragma unroll
-                    for (int v = w + 1; v < 4; ++v) {
-                        const uint32_t more = ~t.run3[v] ? (uint32_t)__builtin_ctzll(~t.run3[v]) : 64u;
-                        const bool go = L == 64u * (uint32_t)(v - w) - p;
-                        L += go ? more : 0u;
-                    }
-                }
+                const uint64_t stop = ~r & ~gtz_low_mask(p); // first byte at or after p that is not in the run
+                const uint32_t L = stop ? (uint32_t)__builtin_ctzll(stop) - p : 64u - p + t.ext[w];
                 cnt.match(L, 4u);
             }
         }
@@ -215,18 +213,8 @@ __device__ __forceinline__ void gtz_emit_tokens(const GtzChunk& c, const GtzToke
                 sink.match(4u * ((e >> 6) & 127u), e >> 13);
             } else if (r & bit) {
                 // distance-4 match: runs on through the following words while their low bytes stay in the run
-                uint32_t L;
                 const uint64_t stop = ~r & ~gtz_low_mask(p); // first byte at or after p that is not in the run
-                if (stop) L = (uint32_t)__builtin_ctzll(stop) - p;
-                else {
-                    L = 64u - p;
-#pragma unroll
-                    for (int v = w + 1; v < 4; ++v) {
-                        const uint32_t more = ~t.run3[v] ? (uint32_t)__builtin_ctzll(~t.run3[v]) : 64u;
-                        const bool go = L == 64u * (uint32_t)(v - w) - p; // still contiguous up to word v
-                        L += go ? more : 0u;
-                    }
-                }
+                const uint32_t L = stop ? (uint32_t)__builtin_ctzll(stop) - p : 64u - p + t.ext[w];
                 sink.match(L, 4u);
             } else {
                 const uint32_t which = p & 3u;
