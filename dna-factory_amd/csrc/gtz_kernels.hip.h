@@ -399,30 +399,50 @@ __global__ __launch_bounds__(GTZ_THREADS) void gtz_encode(const GtzParams p)
     // Key tables, one quarter of the g space at a time: earliest / latest position of every key with 32-bit LDS
     // atomics in a scratch area (the match lists' space, not yet in use), then narrowed to 16 bits -- the tables
     // that stay are 16 KB instead of 32, which is what lets a fourth workgroup share the CU.
+    // A quarter is 256 g-space words, one per thread: the thread slides the 5-cell key over its word's 16 positions
+    // in registers (rows start on word boundaries of the g space, so a word belongs to one row).  Of a run of equal
+    // keys only its first position can be the earliest and only its last the latest, so the others stay away from
+    // the table: long stretches of "0/0" would otherwise send every atomic to one LDS address.
     {
         uint32_t* scr = s->far; // [0, KEYS): earliest, [KEYS, 2 KEYS): latest + 1
+        const uint32_t total_words = s->gw[nr];
         for (uint32_t q = 0; q < (DNAF_GTZ_EXP == 4 ? 0u : GTZ_SEGS); ++q) {
             for (uint32_t t = tid; t < 2 * GTZ_KEYS; t += GTZ_THREADS) scr[t] = t < GTZ_KEYS ? 0xFFFFFFFFu : 0u;
             __syncthreads();
-            const uint32_t qlo = q << GTZ_SEG_SHIFT, qhi = q + 1u == GTZ_SEGS ? 0xFFFFFFFFu : (q + 1u) << GTZ_SEG_SHIFT;
-            for (uint32_t i = 0; i < nr; ++i) {
+            const uint32_t wq = (q << (GTZ_SEG_SHIFT - 4u)) + tid; // this thread's word; the last quarter takes what is left
+            for (uint32_t w = wq; w < total_words; w += GTZ_THREADS) {
+                if (q + 1u < GTZ_SEGS && w != wq) break; // only the last quarter is open-ended
+                uint32_t i = 0;
+                while (i + 1u < nr && s->gw[i + 1] <= w) ++i;
                 const uint32_t kb = s->kb[i], ke = s->ke[i];
-                if (ke - kb < GTZ_KEY_CELLS) continue;
                 const uint32_t gbase = 16u * s->gw[i] - 16u * s->kw0[i];
-                // positions of this row whose g lies in the quarter
-                const uint32_t g_first = gbase + kb, g_end = gbase + ke - GTZ_KEY_CELLS + 1u;
-                const uint32_t lo = max(g_first, qlo), hi = min(g_end, qhi);
-                // Lanes hold consecutive positions.  Of a run of equal keys only its first position can be the
-                // earliest and only its last the latest, so the others stay away from the table: long stretches
-                // of "0/0" would otherwise send every lane's atomic to one LDS address.
-                for (uint32_t gg = lo; gg < hi; gg += GTZ_THREADS) {
-                    const uint32_t g = gg + tid;
-                    const bool live = g < hi;
-                    const uint32_t key = live ? gtz_window(s->cells, g) & (GTZ_KEYS - 1u) : 0xFFFFFFFFu;
-                    const uint32_t before = __shfl_up(key, 1, 64), after = __shfl_down(key, 1, 64);
-                    const uint32_t lane = tid & 63u;
-                    if (live && (lane == 0u || before != key)) atomicMin(&scr[key], g);
-                    if (live && (lane == 63u || after != key)) atomicMax(&scr[GTZ_KEYS + key], g + 1u);
+                // positions of the row at which a whole key lies inside the member: [g_first, g_end)
+                const uint32_t g_first = gbase + kb, g_end = ke - kb < GTZ_KEY_CELLS ? g_first : gbase + ke - GTZ_KEY_CELLS + 1u;
+                const uint32_t g0 = 16u * w;
+                const uint32_t lo = max(g0, g_first), hi = min(g0 + 16u, g_end);
+                const bool any = lo < hi;
+                const uint64_t v = ((uint64_t)s->cells[w + 1] << 32) | s->cells[w];
+                // neighbours across the lanes: the last key of the word before, the first key of the word after
+                const uint32_t key_first = (uint32_t)v & (GTZ_KEYS - 1u), key_last = (uint32_t)(v >> 30) & (GTZ_KEYS - 1u);
+                const bool full = any && lo == g0 && hi == g0 + 16u;
+                const uint32_t lane = tid & 63u;
+                const uint32_t prev_last = __shfl_up(full ? key_last : 0xFFFFFFFFu, 1, 64);
+                const uint32_t next_first = __shfl_down(full ? key_first : 0xFFFFFFFFu, 1, 64);
+                if (any) {
+                    // the key at the position before (0xFFFFFFFF: none that is entered, so this one counts)
+                    uint32_t before = lane && lo == g0 ? prev_last : 0xFFFFFFFFu;
+#pragma unroll
+                    for (uint32_t j = 0; j < 16u; ++j) {
+                        const uint32_t g = g0 + j;
+                        const uint32_t key = (uint32_t)(v >> (2u * j)) & (GTZ_KEYS - 1u);
+                        const bool live = g >= lo && g < hi;
+                        // the key at the position after, if that position is entered too
+                        const uint32_t after = j < 15u ? (g + 1u < hi ? (uint32_t)(v >> (2u * j + 2u)) & (GTZ_KEYS - 1u) : 0xFFFFFFFFu)
+                                                       : (lane < 63u ? next_first : 0xFFFFFFFFu);
+                        if (live && before != key) atomicMin(&scr[key], g);
+                        if (live && after != key) atomicMax(&scr[GTZ_KEYS + key], g + 1u);
+                        before = live ? key : 0xFFFFFFFFu;
+                    }
                 }
             }
             __syncthreads();
