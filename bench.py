@@ -333,7 +333,7 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "frac_of_measured_copy_6290_GBs": achieved / 6290.0, "traffic": traffic,
                          "traffic_source": traffic_source,
                          "bytes_per_launch": bytes_per_launch, "kernel_ms_mean": mean_kernel_s * 1e3,
-                         "launches_timed": n_rec, "kernel": "rowrun_kernel" if a.rng == "philox" else "mt_rowgen_kernel (+ mt_jump_kernel)",
+                         "launches_timed": n_rec, "kernel": ("rowrun_kernel" if S > 2032 else "rowmix_kernel") if a.rng == "philox" else "mt_rowgen_kernel (+ mt_jump_kernel)",
                          "draws_per_s": 2.0 * S * a.tile_rows / mean_kernel_s},
         }
         if a.bgzf_tiles > 0 and (what & capi.OUT_TEXT):
