@@ -22,7 +22,7 @@ namespace dnaf {
 
 constexpr uint32_t MTN = 624, MTM = 397;
 constexpr uint32_t MT_SEQ_WORDS = 19937 + 624 + 8; // words of sequence a jump correlates over
-constexpr uint32_t MT_RING = 1872;                 // 3 slots of one block of tempered words each (2 would do: no faster)
+constexpr uint32_t MT_RING = 2 * 624;              // ring of generator words: the block being consumed and the one before / after it
 
 __device__ __forceinline__ uint32_t mt_twist(uint32_t a, uint32_t b)
 {
@@ -129,12 +129,6 @@ __device__ __forceinline__ uint32_t mt_temper_k(uint32_t y, const MtConsts& k)
     return y;
 }
 
-// One wave: the next block, regenerated in place in ten batches of 64 consecutive words (the last one 48).  Batch b needs
-// the old words 64b .. 64b+64 (the last of them is overwritten by batch b+1, later in program order) and word i+397, which
-// is old up to i = 226 and otherwise the new word i-227 of a batch at least three back; word 623 needs the new word 0.
-// All addresses are `lane + constant` except in the batch where i+397 wraps and for word 623's neighbour: those two index
-// vectors (im3, i1_9) are computed once per kernel.  Each new word is tempered into ringw[i]: the caller passes the slot's
-// first word (slots are 624 words apart, a block never wraps inside the ring).
 // orders this wave's LDS traffic for the compiler (the hardware keeps one wave's LDS operations in order by itself)
 __device__ __forceinline__ void mt_wave_sync()
 {
@@ -143,30 +137,33 @@ __device__ __forceinline__ void mt_wave_sync()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-__device__ __forceinline__ void mt_wave_next_block(uint32_t* st, uint32_t* ringw, uint32_t lane, uint32_t im3, uint32_t i1_9,
-                                                   const MtConsts& k)
+// One wave: the next block of 624 generator words into the ring slot `cur`, from the block before it in slot `prev` -- the
+// ring of (untempered) words the consumer reads IS the generator state, there is no second copy: per new word three LDS
+// reads and one write.  Ten batches of 64 consecutive words (the last one 48).  Word i needs the previous block's words i
+// and i+1 (for i = 623: the NEW word 0) and its word i+397, or from i = 227 on the new word i-227, made at least three
+// batches earlier.  All addresses are `lane + constant` on one of the two slot bases, except in the batch where i+397
+// wraps and for word 623's neighbour (one select each).
+__device__ __forceinline__ void mt_wave_next_block(const uint32_t* prev, uint32_t* cur, uint32_t lane, const MtConsts& k)
 {
-    uint32_t* sp = st + lane;
-    uint32_t* rw = ringw + lane;
-    // The lanes talk to each other through `st`, which the compiler cannot see (to one thread all these addresses are
+    const uint32_t* pp = prev + lane;
+    uint32_t* cp = cur + lane;
+    const uint32_t* at_i1_9 = lane == 47u ? cur : pp + 577u;                        // batch 9: word i + 1
+    const uint32_t* at_im3 = lane < 35u ? pp + (192u + MTM) : cur + (lane - 35u);   // batch 3: word i + 397
+    // The lanes talk to each other through the ring, which the compiler cannot see (to one thread all these addresses are
     // distinct): a wave barrier per batch keeps the memory operations of different batches in program order.  The reads of
     // batch b+1 depend on nothing batch b writes, so they are issued before batch b's arithmetic and land behind it.
-    uint32_t s0 = sp[0], s1 = sp[1], sm = sp[MTM];
+    uint32_t s0 = pp[0], s1 = pp[1], sm = pp[MTM];
 #pragma unroll
     for (uint32_t b = 0; b < 10u; ++b) {
         mt_wave_sync();
         uint32_t n0 = 0, n1 = 0, nm = 0;
         if (b < 8u || (b == 8u && lane < 48u)) {
             const uint32_t c = b + 1u;
-            n0 = sp[64u * c];
-            n1 = c < 9u ? sp[64u * c + 1u] : st[i1_9];
-            nm = c < 3u ? sp[64u * c + MTM] : (c == 3u ? st[im3] : sp[64u * c - (MTN - MTM)]);
+            n0 = pp[64u * c];
+            n1 = c < 9u ? pp[64u * c + 1u] : *at_i1_9;
+            nm = c < 3u ? pp[64u * c + MTM] : (c == 3u ? *at_im3 : cp[64u * c - (MTN - MTM)]);
         }
-        if (b < 9u || lane < 48u) {
-            const uint32_t v = mt_twist_k(s0, s1, sm, k);
-            sp[64u * b] = v;
-            rw[64u * b] = mt_temper_k(v, k);
-        }
+        if (b < 9u || lane < 48u) cp[64u * b] = mt_twist_k(s0, s1, sm, k);
         s0 = n0; s1 = n1; sm = nm;
     }
     mt_wave_sync();
@@ -183,16 +180,15 @@ __device__ __forceinline__ uint64_t mt_thr_key(uint64_t t) { return ((t >> 26) <
 // the per-lane packing cost more instructions than generating the numbers) -- and the comparisons come out as wave masks, from
 // which the packed bytes are cut directly.
 //
-// Ring: three slots of 624 tempered words; a block is always written to a whole slot, and only when fewer than 256 words
-// are left -- those lie in the slot before it.  (Two slots are enough and were measured: 21 instead of 16 waves per CU, no
-// faster -- the kernel runs at a power-limited clock, 2.0-2.2 GHz, with its vector units 75 % busy.)  The first block is used from word
-// start_off on, so the consumer's quads start at indices = start_off (mod 4): the ring is laid into its storage shifted by
-// (-start_off) mod 4 words, which makes every quad 16-byte aligned, and the first three words are mirrored behind the end
-// for the one quad per turn that straddles it.
+// Ring: two slots of 624 untempered generator words, which are at once the generator's state: a block is written to the
+// slot that does not hold the newest block, from the newest block, and only when fewer than 256 words are left to consume
+// -- those lie in the newest block.  The first block (the wave's entry state) is used from word start_off on, so the
+// consumer's quads start at indices = start_off (mod 4): the ring is laid into its storage shifted by (-start_off) mod 4
+// words, which makes every quad 16-byte aligned, and the first three words are mirrored behind the end for the one quad
+// per turn that straddles it.  5 KB of LDS per wave.
 template <bool TEXT, bool PACKED>
 __global__ __launch_bounds__(64) void mt_rowgen_kernel(const MtGenParams mp)
 {
-    __shared__ uint32_t st[MTN + 1];
     __shared__ __attribute__((aligned(16))) uint32_t ring_store[4 + MT_RING + 4];
     const GenParams& p = mp.g;
     const uint32_t lane = threadIdx.x;
@@ -202,14 +198,9 @@ __global__ __launch_bounds__(64) void mt_rowgen_kernel(const MtGenParams mp)
     const uint64_t row_hi = min(p.n_rows, row_lo + mp.rows_per_wave);
     const MtConsts K = mt_consts();
     uint32_t* ring = ring_store + ((4u - (mp.start_off & 3u)) & 3u);
-    // index vectors of the two irregular reads of a block (mt_wave_next_block)
-    const uint32_t im3 = 192u + lane + MTM >= MTN ? 192u + lane + MTM - MTN : 192u + lane + MTM;
-    const uint32_t i1_9 = lane == 47u ? 0u : 577u + lane;
 
-    for (uint32_t i = lane; i < MTN; i += 64u) st[i] = mp.states[wave * MTN + i];
-    mt_wave_sync();
-    // ring bookkeeping in words; all wave-uniform.  The first block sits in slot 0 at its own offsets.
-    for (uint32_t i = mp.start_off + lane; i < MTN; i += 64u) ring[i] = mt_temper_k(st[i], K);
+    // the wave's entry state is the first block, in slot 0; ring bookkeeping in words, all wave-uniform
+    for (uint32_t i = lane; i < MTN; i += 64u) ring[i] = mp.states[wave * MTN + i];
     uint32_t head = MTN, tail = mp.start_off, avail = MTN - mp.start_off;
     mt_wave_sync();
 
@@ -236,39 +227,50 @@ __global__ __launch_bounds__(64) void mt_rowgen_kernel(const MtGenParams mp)
         for (uint32_t sb = 0; sb < S; sb += 64u) {
             const uint32_t need = min(256u, row_words - consumed);
             while (avail < need) { // wave-uniform
-                mt_wave_next_block(st, ring + head, lane, im3, i1_9, K);
+                mt_wave_next_block(ring + (MTN - head), ring + head, lane, K); // head is 0 or 624: the other slot holds the newest block
                 if (head == 0u && lane < 3u) ring[MT_RING + lane] = ring[lane];
-                head = head + MTN == MT_RING ? 0u : head + MTN;
+                head = MTN - head;
                 avail += MTN;
                 mt_wave_sync();
             }
             uint32_t q = tail + 4u * lane;
             q = q >= MT_RING ? q - MT_RING : q;
-            // 16-byte aligned by the ring's shift; lanes past the row's end read words that are not used
-            const uint4 w = *reinterpret_cast<const uint4*>(__builtin_assume_aligned(ring + q, 16));
-            const uint64_t va = mt_roll_key(w.x, w.y), vb = mt_roll_key(w.z, w.w);
+            // 16-byte aligned by the ring's shift; lanes past the row's end read words that are not used.  The ring holds the
+            // generator's words as they are: a roll is hi * 2^26 + lo with hi = temper(a) >> 5 and lo = temper(b) >> 6, and
+            // unless hi EQUALS the high part of a threshold (2^-27 per draw) the low part decides nothing -- so the step below
+            // tempers only the a-words (tempering is 8 of the 13 instructions a word costs) and hands the rare tie, like
+            // every row that is not plain, to the general step, which tempers all four.
+            const uint4 raw = *reinterpret_cast<const uint4*>(__builtin_assume_aligned(ring + q, 16));
+            bool done = false;
             if (plain && sb + 64u < S) {
                 // all 64 samples live, none of them the row's last
-                const uint64_t A = __ballot(va > T0), B = __ballot(vb > T0);
-                if (TEXT) {
-                    const uint32_t cell = DIPLOID_CELL(0u, 0u, 0x09u) + (va > T0 ? 1u : 0u) + (vb > T0 ? 0x10000u : 0u);
-                    store_unaligned<4>(cells + 4ull * sb + 4u * lane, &cell);
-                }
-                if (PACKED) {
-                    // even bits from A, odd bits from B: s_bitreplicate doubles every bit, the masks pick the copy
-                    uint64_t a0, a1, b0, b1;
-                    asm("s_bitreplicate_b64_b32 %0, %1" : "=s"(a0) : "s"((uint32_t)A));
-                    asm("s_bitreplicate_b64_b32 %0, %1" : "=s"(a1) : "s"((uint32_t)(A >> 32)));
-                    asm("s_bitreplicate_b64_b32 %0, %1" : "=s"(b0) : "s"((uint32_t)B));
-                    asm("s_bitreplicate_b64_b32 %0, %1" : "=s"(b1) : "s"((uint32_t)(B >> 32)));
-                    const uint64_t p0 = (a0 & 0x5555555555555555ull) | (b0 & 0xAAAAAAAAAAAAAAAAull);
-                    const uint64_t p1 = (a1 & 0x5555555555555555ull) | (b1 & 0xAAAAAAAAAAAAAAAAull);
-                    if (lane == 0u) {
-                        const uint4 pk = make_uint4((uint32_t)p0, (uint32_t)(p0 >> 32), (uint32_t)p1, (uint32_t)(p1 >> 32));
-                        store_unaligned<16>(prow + (sb >> 2), &pk);
+                const uint32_t ha = mt_temper_k(raw.x, K) >> 5, hb = mt_temper_k(raw.z, K) >> 5, th = (uint32_t)(T0 >> 32);
+                if (__ballot(ha == th || hb == th) == 0ull) { // wave-uniform; otherwise the general step decides with the low parts
+                    done = true;
+                    const uint64_t A = __ballot(ha > th), B = __ballot(hb > th);
+                    if (TEXT) {
+                        const uint32_t cell = DIPLOID_CELL(0u, 0u, 0x09u) + (ha > th ? 1u : 0u) + (hb > th ? 0x10000u : 0u);
+                        store_unaligned<4>(cells + 4ull * sb + 4u * lane, &cell);
+                    }
+                    if (PACKED) {
+                        // even bits from A, odd bits from B: s_bitreplicate doubles every bit, the masks pick the copy
+                        uint64_t a0, a1, b0, b1;
+                        asm("s_bitreplicate_b64_b32 %0, %1" : "=s"(a0) : "s"((uint32_t)A));
+                        asm("s_bitreplicate_b64_b32 %0, %1" : "=s"(a1) : "s"((uint32_t)(A >> 32)));
+                        asm("s_bitreplicate_b64_b32 %0, %1" : "=s"(b0) : "s"((uint32_t)B));
+                        asm("s_bitreplicate_b64_b32 %0, %1" : "=s"(b1) : "s"((uint32_t)(B >> 32)));
+                        const uint64_t p0 = (a0 & 0x5555555555555555ull) | (b0 & 0xAAAAAAAAAAAAAAAAull);
+                        const uint64_t p1 = (a1 & 0x5555555555555555ull) | (b1 & 0xAAAAAAAAAAAAAAAAull);
+                        if (lane == 0u) {
+                            const uint4 pk = make_uint4((uint32_t)p0, (uint32_t)(p0 >> 32), (uint32_t)p1, (uint32_t)(p1 >> 32));
+                            store_unaligned<16>(prow + (sb >> 2), &pk);
+                        }
                     }
                 }
-            } else {
+            }
+            if (!done) {
+                const uint4 w = make_uint4(mt_temper_k(raw.x, K), mt_temper_k(raw.y, K), mt_temper_k(raw.z, K), mt_temper_k(raw.w, K));
+                const uint64_t va = mt_roll_key(w.x, w.y), vb = mt_roll_key(w.z, w.w);
                 const uint32_t i = sb + lane; // this lane's sample
                 const bool live = i < S;
                 // SNPTuples.pick_allele_index (pop_factory.py:92-95): first index whose cumulative frequency is >= the roll

@@ -85,6 +85,36 @@ def _oracle_mt(orc, snps, samples, seed, rng_row0=0, mt_state=None):
 
 
 @pytest.mark.gpu
+def test_gpu_mt19937_rolls_that_tie_with_a_threshold_inside_a_row(RowGenerator, oracle):
+    """The row kernel's 64-sample step looks only at the high 27 bits of a roll and leaves a roll whose high part EQUALS
+    the threshold's to its general step.  Here thresholds are the very doubles numpy draws for samples in the middle of a
+    row (a roll equal to the threshold picks the lower index), their neighbours one ulp down and up, and doubles
+    that share the roll's high 27 bits but differ below."""
+    S, seed, n_rows = 300, 4242, 8
+    numpy_rs = np.random.RandomState(seed)
+    d = [numpy_rs.rand(2 * S) for _ in range(n_rows)]
+    def near(x, k):  # same high 27 bits of the 53-bit numerator, different low 26
+        r = int(x * 2.0**53)
+        return ((r & ~((1 << 26) - 1)) | ((r + k) & ((1 << 26) - 1))) / 2.0**53
+    cums = [float(d[0][40]), float(d[1][41]), float(np.nextafter(d[2][90], 0.0)), float(np.nextafter(d[3][17], 1.0)),
+            near(d[4][66], 1), near(d[5][67], -1), float(d[6][127]), float(d[7][128])]
+    letters = "ACGT"
+    snps = [(r + 1, str(1 + r % 22), 1000 + r, [(letters[r % 4], cums[r]), (letters[(r + 1) % 4], 1.0)]) for r in range(n_rows)]
+    samples = [(1 + (i % 2), True, None) for i in range(S)]
+    want_text, want_off, want_packed = _oracle_mt(oracle, snps, samples, seed)
+    with RowGenerator(device=0, seed=seed, rng="mt19937") as g:
+        g.set_samples(samples)
+        g.set_snps(snps)
+        text, off, packed = g.generate()
+    assert np.array_equal(off, want_off)
+    assert text.tobytes() == want_text
+    assert np.array_equal(packed, want_packed)
+    # the ties are really there: draw 40 of row 0 equals its threshold, so that allele is index 0 ("0"), and one ulp less flips it
+    lines = want_text.decode().split("\n")
+    assert lines[0].split("\t")[9 + 20].split("/")[0] == "0" and lines[2].split("\t")[9 + 45].split("/")[0] == "1"
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("n_rows,S", [(5, 1), (40, 3), (200, 39), (45, 156), (30, 257), (90, 1000), (8, 20000)])
 def test_gpu_mt19937_matches_oracle(RowGenerator, oracle, n_rows, S):
     rs = np.random.RandomState(n_rows * 7 + S)
