@@ -189,7 +189,7 @@ class _Rank:
         gen.set_samples(self.st)
         q = gen.row_quantum
         if a.rng == "mt19937" and q > 1:
-            # a wave owns q rows and holds 10 KB of LDS: 4096 waves are resident at once, so whole rounds of 4096 waves
+            # a wave owns q rows; 8192 waves are resident at once (5 KB of LDS, 8 waves per SIMD): tiles of multiples of 4096 waves
             q *= 4096 if a.tile_rows >= 4096 * q else 1
             self.tile_rows = max(q, (a.tile_rows + q // 2) // q * q)
         else:
