@@ -42,6 +42,17 @@ def test_single_gpu_line_has_the_contract_fields():
     assert r["traffic"] is None and "workload" in r["traffic_source"]  # the committed PMC file is for the default workload
 
 
+def test_mt19937_mode_line():
+    """--rng mt19937: tiles are whole multiples of the stream's row quantum (156 / gcd(S, 156) rows per wave)."""
+    args = ["--rng", "mt19937", "--samples", "2000", "--tile-rows", "20000", "--table-rows", "40000", "--steps", "2", "--warmup", "1",
+            "--cpu-seconds", "0", "--bgzf-tiles", "0"]
+    p = subprocess.run([sys.executable, "bench.py"] + args, cwd=REPO, env=_env(), capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    d = _last_json(p.stdout)
+    assert d["config"]["rng"].startswith("mt19937") and d["config"]["tile_rows"] % 39 == 0 and d["value"] > 0
+    assert "mt_rowgen_kernel" in d["roofline"]["kernel"]
+
+
 def test_gpus_2_stands_alone_without_a_launcher():
     p = subprocess.run([sys.executable, "bench.py", "--gpus", "2"] + SMALL, cwd=REPO, env=_env(DNAF_BENCH_SHARE_GPU="1"),
                        capture_output=True, text=True, timeout=600)
