@@ -167,19 +167,7 @@ __global__ DNAF_MIX_BOUNDS void rowmix_kernel(const GenParams p)
     while (r < nrun) {
         uint32_t lane = lane_id; // an opaque copy per stretch: keeps lane-derived values out of registers across the loop
         asm volatile("" : "+v"(lane));
-        if (!((ord_mask >> r) & 1ull)) {
-            // any other kind of row: a row at a time (rowrun_kernels.hip.h), whole, with this wave's own first and last bytes
-            const RowRec rec = p.recs[p.row_begin + j0 + r];
-            uint8_t* row_text = p.text + (rec.text_off - p.text_base);
-            if (TEXT) {
-                const uint8_t* src = p.prefix + rec.prefix_off;
-                for (uint32_t i = lane; i < rec.prefix_len; i += 64) row_text[i] = src[i];
-            }
-            make_ctx(c, p, rec, j0 + r, row_text);
-            const HeadJob none{};
-            if (rec.n_alleles > 2) run_row_other<TEXT, PACKED, true>(c, rec.cls, 0u, g_stop, lane);
-            else if (rec.cls != 0u) run_row_other<TEXT, PACKED, false>(c, rec.cls, 0u, g_stop, lane);
-            else (void)run_row_biallelic<TEXT, PACKED, false>(c, 0u, g_stop, none, lane); // forced cells
+        if (!((ord_mask >> r) & 1ull)) { // any other kind of row: after the stretches, below
             ++r;
             continue;
         }
@@ -294,6 +282,26 @@ __global__ DNAF_MIX_BOUNDS void rowmix_kernel(const GenParams p)
             }
         }
         r = e;
+    }
+    // The rows of any other kind (X / Y / MT, multi-allelic, forced cells), a row at a time by the code of
+    // rowrun_kernels.hip.h, whole, with this wave's own first and last bytes.  In a loop of their own behind the stretches
+    // rather than between them: as a branch inside the loop above, this rare path's live values pushed the trip loop's
+    // scalars out of their registers (it reloaded them with v_readlane every trip).
+    for (uint64_t left = ~ord_mask & (nrun >= 64u ? ~0ull : (1ull << nrun) - 1ull); left; left &= left - 1ull) {
+        const uint32_t ro = (uint32_t)__builtin_ctzll(left);
+        uint32_t lane = lane_id;
+        asm volatile("" : "+v"(lane));
+        const RowRec rec = p.recs[p.row_begin + j0 + ro];
+        uint8_t* row_text = p.text + (rec.text_off - p.text_base);
+        if (TEXT) {
+            const uint8_t* src = p.prefix + rec.prefix_off;
+            for (uint32_t i = lane; i < rec.prefix_len; i += 64) row_text[i] = src[i];
+        }
+        make_ctx(c, p, rec, j0 + ro, row_text);
+        const HeadJob none{};
+        if (rec.n_alleles > 2) run_row_other<TEXT, PACKED, true>(c, rec.cls, 0u, g_stop, lane);
+        else if (rec.cls != 0u) run_row_other<TEXT, PACKED, false>(c, rec.cls, 0u, g_stop, lane);
+        else (void)run_row_biallelic<TEXT, PACKED, false>(c, 0u, g_stop, none, lane); // forced cells
     }
     MIX_STAMP(3); // the rows
 #ifdef DNAF_MIX_PROFILE
