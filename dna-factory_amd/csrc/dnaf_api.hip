@@ -795,6 +795,7 @@ int dnaf_generate(dnaf_ctx* c, uint64_t row_begin, uint64_t n_rows, uint32_t wha
         }
         while (rpw > 1 && n_rows / rpw < 16384) rpw /= 2;
         if (c->force_rpw) rpw = std::min<uint32_t>(c->force_rpw, 64u);
+        if (c->prefix_stride > 48u) rpw = std::min<uint32_t>(rpw, dnaf::MIX_PFX_BYTES / c->prefix_stride); // the run's fixed columns must fit their LDS cache
     }
     p.rows_per_wave = rpw;
     const uint64_t items = (use_runs || use_mix) ? (n_rows + rpw - 1) / rpw : n_rows * p.nseg;

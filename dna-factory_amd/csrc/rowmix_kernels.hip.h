@@ -23,7 +23,9 @@
 
 namespace dnaf {
 
-struct MixRow {        // what a lane needs of its row, 32 bytes in LDS
+typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+
+struct MixRow {        // what a lane needs of its row (kept in two LDS arrays: the constants, and threshold + cell start)
     uint32_t x0, x1, x2, x3;
     uint32_t t0, cells_rel, pad0, pad1; // cells_rel: the row's first cell byte, relative to the run's first text byte
 };
@@ -39,7 +41,7 @@ __device__ __forceinline__ void divmod_small(uint32_t q, uint32_t d, uint32_t m,
 }
 
 #ifndef DNAF_MIX_PFX_BYTES
-#define DNAF_MIX_PFX_BYTES 4096
+#define DNAF_MIX_PFX_BYTES 3072
 #endif
 #ifndef DNAF_MIX_BOUNDS
 #define DNAF_MIX_BOUNDS __launch_bounds__(256)
@@ -47,7 +49,7 @@ __device__ __forceinline__ void divmod_small(uint32_t q, uint32_t d, uint32_t m,
 #ifndef DNAF_MIX_EXP
 #define DNAF_MIX_EXP 0
 #endif
-constexpr uint32_t MIX_PFX_BYTES = DNAF_MIX_PFX_BYTES; // the fixed columns of a run's rows, cached in LDS (64 rows x 64 bytes)
+constexpr uint32_t MIX_PFX_BYTES = DNAF_MIX_PFX_BYTES; // the fixed columns of a run's rows, cached in LDS (64 rows x 48 bytes, or 48 x 64: the host caps the run)
 constexpr uint32_t MIX_MAX_GROUPS = 509; // the host never sends rows of this many groups or more here (dense pitch: S <= 2,032)
 constexpr uint32_t MIX_STAGE = 768;      // packed bytes of one row handled a row at a time (< MIX_MAX_GROUPS + pad)
 
@@ -79,7 +81,8 @@ __global__ DNAF_MIX_BOUNDS void rowmix_kernel(const GenParams p)
 #endif
     __shared__ u32x4_t cell_lut[256];
     __shared__ __attribute__((aligned(16))) uint8_t pk_stage[4][MIX_STAGE];
-    __shared__ __attribute__((aligned(16))) MixRow rows_all[4][64];
+    __shared__ __attribute__((aligned(16))) u32x4_t xs_all[4][64]; // per row of the run: the four folded Philox constants
+    __shared__ __attribute__((aligned(8))) u32x2_t ts_all[4][64];     // its threshold and where its cells start (cells_rel)
     __shared__ __attribute__((aligned(16))) uint8_t pfx_all[4][MIX_PFX_BYTES];
     if (TEXT) {
         const uint32_t t = threadIdx.x;
@@ -98,7 +101,8 @@ __global__ DNAF_MIX_BOUNDS void rowmix_kernel(const GenParams p)
     const uint32_t nrun = (uint32_t)min((uint64_t)R, p.n_rows - j0);
     const uint32_t G = p.G, S = p.S;
     const uint32_t g_stop = PACKED ? p.W * 4u : G;
-    LDS_PTR(MixRow) tab = (LDS_PTR(MixRow))rows_all[threadIdx.x >> 6];
+    LDS_PTR(u32x4_t) xtab = (LDS_PTR(u32x4_t))xs_all[threadIdx.x >> 6];
+    LDS_PTR(u32x2_t) ttab = (LDS_PTR(u32x2_t))ts_all[threadIdx.x >> 6];
 
     SegCtx c;
     c.lut = (const LDS_PTR(u32x4_t))cell_lut;
@@ -135,8 +139,8 @@ __global__ DNAF_MIX_BOUNDS void rowmix_kernel(const GenParams p)
         e.x0 = rc.x0; e.x1 = rc.x1; e.x2 = rc.x2; e.x3 = rc.x3;
         e.t0 = myrec.thr[0]; e.cells_rel = my_rel + myrec.prefix_len; e.pad0 = e.pad1 = 0;
         if (lane_id < nrun) {
-            *reinterpret_cast<LDS_PTR(u32x4_t)>(&tab[lane_id]) = u32x4_t{e.x0, e.x1, e.x2, e.x3};
-            *reinterpret_cast<LDS_PTR(u32x4_t)>(&tab[lane_id].t0) = u32x4_t{e.t0, e.cells_rel, 0u, 0u};
+            xtab[lane_id] = u32x4_t{e.x0, e.x1, e.x2, e.x3};
+            ttab[lane_id] = u32x2_t{e.t0, e.cells_rel};
         }
     }
     MIX_STAMP(1); // records loaded, row table written
@@ -203,8 +207,8 @@ __global__ DNAF_MIX_BOUNDS void rowmix_kernel(const GenParams p)
         uint32_t row0, g0;
         bool live0;
         coords(0u, row0, g0, live0);
-        u32x4_t xs0 = *reinterpret_cast<const LDS_PTR(u32x4_t)>(&tab[row0]);
-        u32x4_t ts0 = *reinterpret_cast<const LDS_PTR(u32x4_t)>(&tab[row0].t0);
+        u32x4_t xs0 = xtab[row0];
+        u32x2_t ts0 = ttab[row0];
         bool have_prev = false, live_prev = false, last_prev = false;
         u32x4_t w_prev = {0, 0, 0, 0};
         uint32_t off_prev = 0;
@@ -225,8 +229,8 @@ __global__ DNAF_MIX_BOUNDS void rowmix_kernel(const GenParams p)
         };
         // one trip at qb with the current coordinates / table entries (row0, g0, live0, xs0, ts0); those of the trip after it
         // are produced into (row1, ...).  Called alternately with the two register sets, so nothing is copied between trips.
-        auto trip = [&](uint32_t qb, uint32_t row0, uint32_t g0, bool live0, const u32x4_t& xs0, const u32x4_t& ts0, uint32_t& row1,
-                        uint32_t& g1, bool& live1, u32x4_t& xs1, u32x4_t& ts1) {
+        auto trip = [&](uint32_t qb, uint32_t row0, uint32_t g0, bool live0, const u32x4_t& xs0, const u32x2_t& ts0, uint32_t& row1,
+                        uint32_t& g1, bool& live1, u32x4_t& xs1, u32x2_t& ts1) {
             if (qb + 64u < n) { // wave-uniform
                 // one trip on: no division, the lane's group moves by 64 mod G and its row by 64 / G (+ 1 when the group wraps)
                 const uint32_t gs = g0 + step_groups;
@@ -234,8 +238,8 @@ __global__ DNAF_MIX_BOUNDS void rowmix_kernel(const GenParams p)
                 g1 = wrap ? gs - G : gs;
                 row1 = row0 + step_rows + (wrap ? 1u : 0u);
                 live1 = qb + 64u + lane < n;
-                xs1 = *reinterpret_cast<const LDS_PTR(u32x4_t)>(&tab[row1]);
-                ts1 = *reinterpret_cast<const LDS_PTR(u32x4_t)>(&tab[row1].t0);
+                xs1 = xtab[row1];
+                ts1 = ttab[row1];
             }
             if (TEXT && pfx_cached) {
                 // fixed columns of the rows that begin in this trip (pop_factory.py:503-507, formatted on the host)
@@ -267,7 +271,8 @@ __global__ DNAF_MIX_BOUNDS void rowmix_kernel(const GenParams p)
         {
             uint32_t row1 = row0, g1 = g0;
             bool live1 = false;
-            u32x4_t xs1 = xs0, ts1 = ts0;
+            u32x4_t xs1 = xs0;
+            u32x2_t ts1 = ts0;
             for (uint32_t qb = 0; qb < n; qb += 128u) {
                 trip(qb, row0, g0, live0, xs0, ts0, row1, g1, live1, xs1, ts1);
                 if (qb + 64u < n) trip(qb + 64u, row1, g1, live1, xs1, ts1, row0, g0, live0, xs0, ts0);

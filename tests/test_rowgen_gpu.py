@@ -334,6 +334,19 @@ def test_short_rows_with_long_fixed_columns(RowGenerator, oracle, share_long):
     check_case(RowGenerator, oracle, snps, samples, seed=int(rs.randint(0, 2**31)))
 
 
+def test_short_rows_with_fixed_columns_of_49_to_64_bytes(RowGenerator, oracle):
+    """13-digit ids with ordinary alleles: the fixed-stride copy of the fixed columns then has a stride of 64 bytes and a
+    wave's run is capped at 48 rows so that they fit their LDS cache."""
+    rs = np.random.RandomState(4964)
+    snps, samples = random_case(rs, 300, 90, p_sex_chrom=0.1, n_del=0)
+    snps = [(i + 10**12, ch, 200000000 + pos % 49000000, tu) for (i, ch, pos, tu) in snps]
+    from dna_factory_amd.tables import SnpTable
+
+    po = np.asarray(SnpTable.from_snps(snps).prefixes()[1])
+    assert 48 < int((po[1:] - po[:-1]).max()) <= 64
+    check_case(RowGenerator, oracle, snps, samples, seed=31)
+
+
 @pytest.mark.parametrize("S", [2029, 2032, 2033, 2036])
 def test_shapes_around_the_dense_pitch_limit(RowGenerator, oracle, S):
     """2,032 samples = 127 packed words per row is the last dense pitch (short-row form); from 2,033 on the rows are padded
