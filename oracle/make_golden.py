@@ -339,6 +339,7 @@ def main():
         return
     if "--only-long-rows" in sys.argv:  # rows long enough for the line-owning GPU kernel (S >= 2,033), several rows per wave
         case_mixed(pf_mod, "mixed_60x2100", 60, 2100, 424242, numpy.random.RandomState(3))
+        case_mixed(pf_mod, "mixed_90x1000", 90, 1000, 31337, numpy.random.RandomState(4))  # short-row kernel, four trips per row
         return
     # the reference's own known answers, test/unit/pop_factory_test.py:24-28
     t = make_snp(pf_mod, 100, "1", 50000, [("G", 0.70), ("A", 0.90), ("T", 1.0)])
@@ -346,6 +347,7 @@ def main():
     case_mixed(pf_mod, "mixed_64x97", 64, 97, 12345, numpy.random.RandomState(1))
     case_mixed(pf_mod, "mixed_150x260", 150, 260, 86399, numpy.random.RandomState(2))
     case_mixed(pf_mod, "mixed_60x2100", 60, 2100, 424242, numpy.random.RandomState(3))
+    case_mixed(pf_mod, "mixed_90x1000", 90, 1000, 31337, numpy.random.RandomState(4))
     case_threshold_equality(pf_mod)
     case_ragged(pf_mod)
     case_full_flow(pf_mod)
