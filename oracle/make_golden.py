@@ -163,6 +163,33 @@ def case_mixed(pf_mod, name, n_rows, S, seed, rs):
     dump(name, snps, spec, seed, run_worker_mt(pf_mod, fam, snps, seed), run_worker_philox(pf_mod, fam, snps, seed))
 
 
+def case_headline_shape(pf_mod):
+    """Ten rows at the headline shape (20,000 samples: one row per wave in the line-owning GPU kernel, whose waves also
+    write the first bytes of the next wave's row), every chromosome class among them, a three-allele row, forced cells."""
+    S, seed = 20000, 20261004
+    rs = numpy.random.RandomState(5)
+    chroms = ["1", "2", "X", "3", "Y", "4", "MT", "5", "22", "X"]
+    letters = ["A", "C", "G", "T"]
+    snps = []
+    for j, chrom in enumerate(chroms):
+        perm = list(rs.permutation(letters))
+        maf = 0.005 * rs.randint(1, 100)
+        tuples = [(perm[0], 0.70), (perm[1], 0.90), (perm[2], 1.0)] if j == 7 else [(perm[0], 1 - maf), (perm[1], 1.0)]
+        snps.append(make_snp(pf_mod, 7000 + 13 * j, chrom, int(rs.randint(0, 250000000)), tuples))
+    ids = [s.id for s in snps]
+    n_ctrl = S // 2
+    spec = []
+    for i in range(S):
+        ctrl = i < n_ctrl
+        sex = 1 if rs.rand() <= 0.5 else 2
+        carried = None
+        if not ctrl:
+            carried = {int(ids[k]): 0.5 for k in ((1, 4, 9) if i % 97 == 0 else (3,) if i % 389 == 0 else ())}
+        spec.append((100001 + i if ctrl else 500001 + i, sex, ctrl, carried))
+    fam = make_samples(pf_mod, spec)
+    dump("headline_10x20000", snps, spec, seed, run_worker_mt(pf_mod, fam, snps, seed), run_worker_philox(pf_mod, fam, snps, seed))
+
+
 def case_threshold_equality(pf_mod):
     """Rolls exactly equal to a threshold pick the LOWER index (`>=`), in both RNG modes."""
     S, seed = 12, 4242
@@ -340,6 +367,7 @@ def main():
     if "--only-long-rows" in sys.argv:  # rows long enough for the line-owning GPU kernel (S >= 2,033), several rows per wave
         case_mixed(pf_mod, "mixed_60x2100", 60, 2100, 424242, numpy.random.RandomState(3))
         case_mixed(pf_mod, "mixed_90x1000", 90, 1000, 31337, numpy.random.RandomState(4))  # short-row kernel, four trips per row
+        case_headline_shape(pf_mod)
         return
     # the reference's own known answers, test/unit/pop_factory_test.py:24-28
     t = make_snp(pf_mod, 100, "1", 50000, [("G", 0.70), ("A", 0.90), ("T", 1.0)])
@@ -348,6 +376,7 @@ def main():
     case_mixed(pf_mod, "mixed_150x260", 150, 260, 86399, numpy.random.RandomState(2))
     case_mixed(pf_mod, "mixed_60x2100", 60, 2100, 424242, numpy.random.RandomState(3))
     case_mixed(pf_mod, "mixed_90x1000", 90, 1000, 31337, numpy.random.RandomState(4))
+    case_headline_shape(pf_mod)
     case_threshold_equality(pf_mod)
     case_ragged(pf_mod)
     case_full_flow(pf_mod)
