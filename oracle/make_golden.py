@@ -163,18 +163,18 @@ def case_mixed(pf_mod, name, n_rows, S, seed, rs):
     dump(name, snps, spec, seed, run_worker_mt(pf_mod, fam, snps, seed), run_worker_philox(pf_mod, fam, snps, seed))
 
 
-def case_headline_shape(pf_mod):
+def case_headline_shape(pf_mod, name="headline_10x20000", S=20000, seed=20261004, chroms=("1", "2", "X", "3", "Y", "4", "MT", "5", "22", "X"), rs_seed=5):
     """Ten rows at the headline shape (20,000 samples: one row per wave in the line-owning GPU kernel, whose waves also
-    write the first bytes of the next wave's row), every chromosome class among them, a three-allele row, forced cells."""
-    S, seed = 20000, 20261004
-    rs = numpy.random.RandomState(5)
-    chroms = ["1", "2", "X", "3", "Y", "4", "MT", "5", "22", "X"]
+    write the first bytes of the next wave's row), every chromosome class among them, a three-allele row, forced cells.
+    Also called for four rows at BASELINE config 5's 50,000 samples (rows of seven 2,048-group segments)."""
+    rs = numpy.random.RandomState(rs_seed)
+    chroms = list(chroms)
     letters = ["A", "C", "G", "T"]
     snps = []
     for j, chrom in enumerate(chroms):
         perm = list(rs.permutation(letters))
         maf = 0.005 * rs.randint(1, 100)
-        tuples = [(perm[0], 0.70), (perm[1], 0.90), (perm[2], 1.0)] if j == 7 else [(perm[0], 1 - maf), (perm[1], 1.0)]
+        tuples = [(perm[0], 0.70), (perm[1], 0.90), (perm[2], 1.0)] if j == 7 or (len(chroms) < 8 and j == 1) else [(perm[0], 1 - maf), (perm[1], 1.0)]
         snps.append(make_snp(pf_mod, 7000 + 13 * j, chrom, int(rs.randint(0, 250000000)), tuples))
     ids = [s.id for s in snps]
     n_ctrl = S // 2
@@ -184,10 +184,10 @@ def case_headline_shape(pf_mod):
         sex = 1 if rs.rand() <= 0.5 else 2
         carried = None
         if not ctrl:
-            carried = {int(ids[k]): 0.5 for k in ((1, 4, 9) if i % 97 == 0 else (3,) if i % 389 == 0 else ())}
+            carried = {int(ids[k % len(ids)]): 0.5 for k in ((1, 4, 9) if i % 97 == 0 else (3,) if i % 389 == 0 else ())}
         spec.append((100001 + i if ctrl else 500001 + i, sex, ctrl, carried))
     fam = make_samples(pf_mod, spec)
-    dump("headline_10x20000", snps, spec, seed, run_worker_mt(pf_mod, fam, snps, seed), run_worker_philox(pf_mod, fam, snps, seed))
+    dump(name, snps, spec, seed, run_worker_mt(pf_mod, fam, snps, seed), run_worker_philox(pf_mod, fam, snps, seed))
 
 
 def case_threshold_equality(pf_mod):
@@ -368,6 +368,7 @@ def main():
         case_mixed(pf_mod, "mixed_60x2100", 60, 2100, 424242, numpy.random.RandomState(3))
         case_mixed(pf_mod, "mixed_90x1000", 90, 1000, 31337, numpy.random.RandomState(4))  # short-row kernel, four trips per row
         case_headline_shape(pf_mod)
+        case_headline_shape(pf_mod, "config5_shape_4x50000", 50000, 77, ("7", "X", "19", "MT"), 6)
         return
     # the reference's own known answers, test/unit/pop_factory_test.py:24-28
     t = make_snp(pf_mod, 100, "1", 50000, [("G", 0.70), ("A", 0.90), ("T", 1.0)])
@@ -377,6 +378,7 @@ def main():
     case_mixed(pf_mod, "mixed_60x2100", 60, 2100, 424242, numpy.random.RandomState(3))
     case_mixed(pf_mod, "mixed_90x1000", 90, 1000, 31337, numpy.random.RandomState(4))
     case_headline_shape(pf_mod)
+    case_headline_shape(pf_mod, "config5_shape_4x50000", 50000, 77, ("7", "X", "19", "MT"), 6)
     case_threshold_equality(pf_mod)
     case_ragged(pf_mod)
     case_full_flow(pf_mod)

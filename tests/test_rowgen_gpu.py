@@ -51,6 +51,23 @@ def test_hip_matches_reference_fixture(RowGenerator, name):
         assert g.lines() == doc["lines_philox"]
 
 
+@pytest.mark.parametrize("name", ["headline_10x20000", "config5_shape_4x50000"])
+@pytest.mark.parametrize("form", ["segments", "line_owning"])
+def test_long_row_fixtures_in_both_kernel_forms(RowGenerator, monkeypatch, name, form):
+    """The reference's own lines at 20,000 and 50,000 samples (BASELINE configs 3 and 5) from both long-row kernel forms: a
+    wave per row segment (what a range of a few rows gets by default) and the line-owning form (what a full tile gets)."""
+    if form == "segments":
+        monkeypatch.setenv("DNAF_FORCE_SEGMENTS", "1")
+    else:
+        monkeypatch.setenv("DNAF_MIN_RUN_WAVES", "0")
+    doc = load_golden(name)
+    snps, samples = golden_inputs(doc)
+    with RowGenerator(device=0, seed=doc["seed"]) as g:
+        g.set_samples(samples)
+        g.set_snps(snps)
+        assert g.lines() == doc["lines_philox"]
+
+
 @pytest.mark.parametrize("n_rows,S", [(1, 1), (7, 3), (33, 64), (50, 257), (40, 1000), (12, 4099), (3, 20000)])
 def test_hip_matches_oracle_random(RowGenerator, oracle, n_rows, S):
     rs = np.random.RandomState(1000 + n_rows + S)
