@@ -278,8 +278,9 @@ def case_full_flow(pf_mod):
     dump("full_flow_120x400", pf.ordered_snps, spec, 20261, lines_mt, lines_ph, extra)
 
 
-def case_config1(pf_mod):
-    """BASELINE config 1 at its stated size through the UNMODIFIED reference: `pop_factory.py -s 100 -c 100 -x 100000
+def case_config1(pf_mod, name="config1", n_controls=100, n_cases=100, max_snps=100000):
+    """(With other arguments: BASELINE config 2, `-s 1000 -c 1000 -x 1000000`, about an hour of the reference's worker.)
+    BASELINE config 1 at its stated size through the UNMODIFIED reference: `pop_factory.py -s 100 -c 100 -x 100000
     -f 0.01 -n 1` = PopulationFactory(num_processes=1, ...).generate_population(100, 100, 0.01, 100000, 6), with the
     three things a test cannot otherwise fix pinned from outside: the wall clock the reference takes its numpy seed and
     its ##filedate from (pop_factory.datetime frozen at 12:34:56 -> numpy.random.seed(123456), pop_factory.py:235),
@@ -322,7 +323,7 @@ def case_config1(pf_mod):
             return False
 
     seed = 123456
-    tmp = tempfile.mkdtemp(prefix="dnaf_config1_")
+    tmp = tempfile.mkdtemp(prefix="dnaf_%s_" % name)
     old_dt, old_writer = pf_mod.datetime, pf_mod.bgzf.BgzfWriter
     pf_mod.datetime = FrozenDatetime
     pf_mod.bgzf.BgzfWriter = HashingWriter
@@ -332,7 +333,7 @@ def case_config1(pf_mod):
     try:
         pf = pf_mod.PopulationFactory(num_processes=1, generate_snps=True, male_odds=0.5, deleterious_config="deleterious.yml",
                                       output_path=tmp)
-        pf.generate_population(100, 100, 0.01, 100000, 6)
+        pf.generate_population(n_controls, n_cases, 0.01, max_snps, 6)
     finally:
         os.chdir(cwd)
         pf_mod.datetime, pf_mod.bgzf.BgzfWriter = old_dt, old_writer
@@ -343,7 +344,7 @@ def case_config1(pf_mod):
         return {"sha256": hashlib.sha256(data).hexdigest(), "bytes": len(data)}
 
     doc = {
-        "command": "pop_factory.py -s 100 -c 100 -x 100000 -f 0.01 -n 1  (reference, unmodified; clock frozen at 12:34:56)",
+        "command": "pop_factory.py -s %d -c %d -x %d -f 0.01 -n 1  (reference, unmodified; clock frozen at 12:34:56)" % (n_controls, n_cases, max_snps),
         "numpy_seed": seed, "python_random_seed": seed,
         "vcf_without_filedate": {"sha256": HashingWriter.digest, "bytes": HashingWriter.n_bytes, "lines": HashingWriter.n_lines,
                                  "first_body_line_head": HashingWriter.first_body_line},
@@ -352,7 +353,7 @@ def case_config1(pf_mod):
         "deleterious_json": sha(os.path.join(tmp, "deleterious.json")),
         "snps_json_decompressed": sha(os.path.join(tmp, "snps.json.gz"), gzip.open),
     }
-    path = os.path.join(GOLD, "config1_sha256.json")
+    path = os.path.join(GOLD, "%s_sha256.json" % name)
     with open(path, "w") as f:
         json.dump(doc, f, indent=1)
     print("wrote %s: %s" % (path, json.dumps(doc["vcf_without_filedate"])))
@@ -363,6 +364,9 @@ def main():
     pf_mod = import_reference()
     if "--only-config1" in sys.argv:
         case_config1(pf_mod)
+        return
+    if "--only-config2" in sys.argv:  # not part of a default run: an hour
+        case_config1(pf_mod, "config2", 1000, 1000, 1000000)
         return
     if "--only-long-rows" in sys.argv:  # rows long enough for the line-owning GPU kernel (S >= 2,033), several rows per wave
         case_mixed(pf_mod, "mixed_60x2100", 60, 2100, 424242, numpy.random.RandomState(3))

@@ -273,9 +273,15 @@ def test_two_shards_give_the_same_vcf_and_bed(tmp_path):
     assert not [f for f in os.listdir(two) if "shard" in f]
 
 
-# ---- BASELINE config 1 at its stated size, against the unmodified reference CLI (tests/golden/config1_sha256.json) ----
-def _config1_golden():
-    with open(os.path.join(REPO, "tests", "golden", "config1_sha256.json")) as f:
+# ---- BASELINE configs 1 and 2 at their stated sizes, against the unmodified reference CLI (tests/golden/config*_sha256.json) ----
+CONFIGS = {"config1": (100, 100, 100000), "config2": (1000, 1000, 1000000)}
+
+
+def _config_golden(name):
+    path = os.path.join(REPO, "tests", "golden", "%s_sha256.json" % name)
+    if not os.path.exists(path):
+        pytest.skip("%s: no hash fixture (oracle/make_golden.py --only-%s)" % (name, name))
+    with open(path) as f:
         return json.load(f)
 
 
@@ -285,24 +291,26 @@ def _sha(data):
     return {"sha256": hashlib.sha256(data).hexdigest(), "bytes": len(data)}
 
 
-def test_config1_host_files_equal_the_reference(cli, tmp_path):
-    """`-s 100 -c 100 -x 100000 -f 0.01` at the reference's seeds (numpy 123456 from its frozen clock, python random the
+@pytest.mark.parametrize("config", sorted(CONFIGS))
+def test_config_host_files_equal_the_reference(cli, tmp_path, config):
+    """`-s 100 -c 100 -x 100000 -f 0.01` (config 1; config 2: `-s 1000 -c 1000 -x 1000000`) at the reference's seeds (numpy 123456 from its frozen clock, python random the
     same): snps.json.gz, deleterious.json, population.fam and pop_deleterious.txt of this build hash to what the
     unmodified reference wrote (oracle/make_golden.py case_config1).  Host side only: runs without a GPU."""
     import random
 
     from dna_factory_amd import population as pop
 
-    gold = _config1_golden()
+    gold = _config_golden(config)
+    n_ctrl, n_cases, n_snps = CONFIGS[config]
     seed = gold["numpy_seed"]
     np.random.seed(seed)
     random.seed(gold["python_random_seed"])
     out = str(tmp_path) + os.path.sep
-    tb = pop.sort_snp_table(pop.generate_snp_table(100000, min_maf=0.01))
+    tb = pop.sort_snp_table(pop.generate_snp_table(n_snps, min_maf=0.01))
     pop.write_snps_file(tb, out + "snps.json.gz")
     groups = pop.pick_deleterious(tb, os.path.join(REPO, "deleterious.yml"))
     pop.write_deleterious_json(groups, out + "deleterious.json")
-    pop.build_samples(groups, 100, 100, 0.5, out, offset=0)
+    pop.build_samples(groups, n_ctrl, n_cases, 0.5, out, offset=0)
     assert _sha(gzip.open(out + "snps.json.gz", "rb").read()) == gold["snps_json_decompressed"]
     assert _sha(open(out + "deleterious.json", "rb").read()) == gold["deleterious_json"]
     assert _sha(open(out + "population.fam", "rb").read()) == gold["population_fam"]
@@ -310,13 +318,15 @@ def test_config1_host_files_equal_the_reference(cli, tmp_path):
 
 
 @pytest.mark.gpu
-def test_config1_whole_output_directory_equals_the_reference(cli, tmp_path):
+@pytest.mark.parametrize("config", sorted(CONFIGS))
+def test_config_whole_output_directory_equals_the_reference(cli, tmp_path, config):
     """BASELINE config 1 end to end: `pop_factory.py -s 100 -c 100 -x 100000 -f 0.01 -n 1 --rng mt19937 --seed 123456`
     writes the VCF (200 samples x 100,000 SNPs, every byte but the ##filedate line) and the four side files of the
-    unmodified reference run at the same seeds."""
-    gold = _config1_golden()
-    out = str(tmp_path / "c1")
-    p = _run_cli(["-s", "100", "-c", "100", "-x", "100000", "-f", "0.01", "-n", "1", "--rng", "mt19937", "--seed",
+    unmodified reference run at the same seeds.  Config 2 likewise (2,000 samples x 1,000,000 SNPs: 8 GB of VCF text)."""
+    gold = _config_golden(config)
+    n_ctrl, n_cases, n_snps = CONFIGS[config]
+    out = str(tmp_path / config)
+    p = _run_cli(["-s", str(n_ctrl), "-c", str(n_cases), "-x", str(n_snps), "-f", "0.01", "-n", "1", "--rng", "mt19937", "--seed",
                   str(gold["numpy_seed"]), "--outdir", out])
     assert p.returncode == 0, p.stderr[-3000:]
     import hashlib
