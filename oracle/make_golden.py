@@ -368,6 +368,9 @@ def main():
     if "--only-config2" in sys.argv:  # not part of a default run: an hour
         case_config1(pf_mod, "config2", 1000, 1000, 1000000)
         return
+    if "--only-config3-1pct" in sys.argv:  # BASELINE config 3's samples and flow at 1 % of its SNPs (the whole would be 40 h)
+        case_config1(pf_mod, "config3_1pct", 10000, 10000, 50000)
+        return
     if "--only-long-rows" in sys.argv:  # rows long enough for the line-owning GPU kernel (S >= 2,033), several rows per wave
         case_mixed(pf_mod, "mixed_60x2100", 60, 2100, 424242, numpy.random.RandomState(3))
         case_mixed(pf_mod, "mixed_90x1000", 90, 1000, 31337, numpy.random.RandomState(4))  # short-row kernel, four trips per row

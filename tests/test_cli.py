@@ -274,13 +274,14 @@ def test_two_shards_give_the_same_vcf_and_bed(tmp_path):
 
 
 # ---- BASELINE configs 1 and 2 at their stated sizes, against the unmodified reference CLI (tests/golden/config*_sha256.json) ----
-CONFIGS = {"config1": (100, 100, 100000), "config2": (1000, 1000, 1000000)}
+CONFIGS = {"config1": (100, 100, 100000), "config2": (1000, 1000, 1000000),
+           "config3_1pct": (10000, 10000, 50000)}  # config 3's 20,000 samples and flow at 1 % of its SNPs (all of it: 40 h of the reference)
 
 
 def _config_golden(name):
     path = os.path.join(REPO, "tests", "golden", "%s_sha256.json" % name)
     if not os.path.exists(path):
-        pytest.skip("%s: no hash fixture (oracle/make_golden.py --only-%s)" % (name, name))
+        pytest.skip("%s: no hash fixture (oracle/make_golden.py --only-%s)" % (name, name.replace("_", "-")))
     with open(path) as f:
         return json.load(f)
 
