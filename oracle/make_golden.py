@@ -278,7 +278,7 @@ def case_full_flow(pf_mod):
     dump("full_flow_120x400", pf.ordered_snps, spec, 20261, lines_mt, lines_ph, extra)
 
 
-def case_config1(pf_mod, name="config1", n_controls=100, n_cases=100, max_snps=100000):
+def case_config1(pf_mod, name="config1", n_controls=100, n_cases=100, max_snps=100000, yml_text=None):
     """(With other arguments: BASELINE config 2, `-s 1000 -c 1000 -x 1000000`, about an hour of the reference's worker.)
     BASELINE config 1 at its stated size through the UNMODIFIED reference: `pop_factory.py -s 100 -c 100 -x 100000
     -f 0.01 -n 1` = PopulationFactory(num_processes=1, ...).generate_population(100, 100, 0.01, 100000, 6), with the
@@ -330,8 +330,13 @@ def case_config1(pf_mod, name="config1", n_controls=100, n_cases=100, max_snps=1
     random.seed(seed)
     cwd = os.getcwd()
     os.chdir(REF)  # -p deleterious.yml is cwd-relative
+    yml = "deleterious.yml"
+    if yml_text is not None:  # a deleterious-group file of this case's own (kept in the fixture, the test writes it out again)
+        yml = os.path.join(tmp, "groups.yml")
+        with open(yml, "w") as f:
+            f.write(yml_text)
     try:
-        pf = pf_mod.PopulationFactory(num_processes=1, generate_snps=True, male_odds=0.5, deleterious_config="deleterious.yml",
+        pf = pf_mod.PopulationFactory(num_processes=1, generate_snps=True, male_odds=0.5, deleterious_config=yml,
                                       output_path=tmp)
         pf.generate_population(n_controls, n_cases, 0.01, max_snps, 6)
     finally:
@@ -353,10 +358,36 @@ def case_config1(pf_mod, name="config1", n_controls=100, n_cases=100, max_snps=1
         "deleterious_json": sha(os.path.join(tmp, "deleterious.json")),
         "snps_json_decompressed": sha(os.path.join(tmp, "snps.json.gz"), gzip.open),
     }
+    if yml_text is not None:
+        doc["deleterious_yml"] = yml_text
+        doc["command"] = doc["command"].replace(" -n 1", " -n 1 -p groups.yml")
     path = os.path.join(GOLD, "%s_sha256.json" % name)
     with open(path, "w") as f:
         json.dump(doc, f, indent=1)
     print("wrote %s: %s" % (path, json.dumps(doc["vcf_without_filedate"])))
+
+
+# four deleterious groups for the config-5-shaped run (polygenic stress): different sizes, weights and frequency windows
+FOUR_GROUPS_YML = """\
+stress_a:
+  mutation_weights: [1, 1]
+  num_instances: 1
+  population_weight: 1
+stress_b:
+  mutation_weights: [0.5, 0.5, 0.5]
+  num_instances: 1
+  population_weight: 2
+  max_minor_allele_freq: 0.30
+stress_c:
+  mutation_weights: [0.2, 0.2, 0.3, 0.3, 0.4]
+  num_instances: 1
+  population_weight: 1
+  min_minor_allele_freq: 0.05
+stress_d:
+  mutation_weights: [1]
+  num_instances: 1
+  population_weight: 1
+"""
 
 
 def main():
@@ -367,6 +398,9 @@ def main():
         return
     if "--only-config2" in sys.argv:  # not part of a default run: an hour
         case_config1(pf_mod, "config2", 1000, 1000, 1000000)
+        return
+    if "--only-config5-1pct" in sys.argv:  # BASELINE config 5's 50,000 samples and four deleterious groups at 1 % of its SNPs
+        case_config1(pf_mod, "config5_1pct", 25000, 25000, 10000, FOUR_GROUPS_YML)
         return
     if "--only-config3-1pct" in sys.argv:  # BASELINE config 3's samples and flow at 1 % of its SNPs (the whole would be 40 h)
         case_config1(pf_mod, "config3_1pct", 10000, 10000, 50000)

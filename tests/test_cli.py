@@ -165,7 +165,12 @@ def test_cli_mt19937_continues_the_numpy_stream(oracle, tmp_path):
     numpy.random.seed(86399)
     random.seed(86399)
     tb = pop.sort_snp_table(pop.generate_snp_table(700, min_maf=0.01))
-    groups = pop.pick_deleterious(tb, os.path.join(REPO, "deleterious.yml"))
+    yml = os.path.join(REPO, "deleterious.yml")
+    if "deleterious_yml" in gold:
+        yml = out + "groups.yml"
+        with open(yml, "w") as f:
+            f.write(gold["deleterious_yml"])
+    groups = pop.pick_deleterious(tb, yml)
     pop.build_samples(groups, 22, 30, 0.5, str(tmp_path))
     st = numpy.random.get_state()
     snps = []
@@ -275,7 +280,8 @@ def test_two_shards_give_the_same_vcf_and_bed(tmp_path):
 
 # ---- BASELINE configs 1 and 2 at their stated sizes, against the unmodified reference CLI (tests/golden/config*_sha256.json) ----
 CONFIGS = {"config1": (100, 100, 100000), "config2": (1000, 1000, 1000000),
-           "config3_1pct": (10000, 10000, 50000)}  # config 3's 20,000 samples and flow at 1 % of its SNPs (all of it: 40 h of the reference)
+           "config3_1pct": (10000, 10000, 50000),  # config 3's 20,000 samples and flow at 1 % of its SNPs (all of it: 40 h of the reference)
+           "config5_1pct": (25000, 25000, 10000)}  # config 5's 50,000 samples and four deleterious groups (the fixture holds the YAML)
 
 
 def _config_golden(name):
@@ -309,7 +315,12 @@ def test_config_host_files_equal_the_reference(cli, tmp_path, config):
     out = str(tmp_path) + os.path.sep
     tb = pop.sort_snp_table(pop.generate_snp_table(n_snps, min_maf=0.01))
     pop.write_snps_file(tb, out + "snps.json.gz")
-    groups = pop.pick_deleterious(tb, os.path.join(REPO, "deleterious.yml"))
+    yml = os.path.join(REPO, "deleterious.yml")
+    if "deleterious_yml" in gold:
+        yml = out + "groups.yml"
+        with open(yml, "w") as f:
+            f.write(gold["deleterious_yml"])
+    groups = pop.pick_deleterious(tb, yml)
     pop.write_deleterious_json(groups, out + "deleterious.json")
     pop.build_samples(groups, n_ctrl, n_cases, 0.5, out, offset=0)
     assert _sha(gzip.open(out + "snps.json.gz", "rb").read()) == gold["snps_json_decompressed"]
@@ -327,8 +338,12 @@ def test_config_whole_output_directory_equals_the_reference(cli, tmp_path, confi
     gold = _config_golden(config)
     n_ctrl, n_cases, n_snps = CONFIGS[config]
     out = str(tmp_path / config)
+    extra = []
+    if "deleterious_yml" in gold:
+        (tmp_path / "groups.yml").write_text(gold["deleterious_yml"])
+        extra = ["-p", str(tmp_path / "groups.yml")]
     p = _run_cli(["-s", str(n_ctrl), "-c", str(n_cases), "-x", str(n_snps), "-f", "0.01", "-n", "1", "--rng", "mt19937", "--seed",
-                  str(gold["numpy_seed"]), "--outdir", out])
+                  str(gold["numpy_seed"]), "--outdir", out] + extra)
     assert p.returncode == 0, p.stderr[-3000:]
     import hashlib
 
