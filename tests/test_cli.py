@@ -330,18 +330,21 @@ def test_config_host_files_equal_the_reference(cli, tmp_path, config):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("config", sorted(CONFIGS))
+@pytest.mark.parametrize("config", sorted(CONFIGS) + ["config3_1pct@4shards"])
 def test_config_whole_output_directory_equals_the_reference(cli, tmp_path, config):
     """BASELINE config 1 end to end: `pop_factory.py -s 100 -c 100 -x 100000 -f 0.01 -n 1 --rng mt19937 --seed 123456`
     writes the VCF (200 samples x 100,000 SNPs, every byte but the ##filedate line) and the four side files of the
     unmodified reference run at the same seeds.  Config 2 likewise (2,000 samples x 1,000,000 SNPs: 8 GB of VCF text)."""
+    extra = []
+    if config.endswith("@4shards"):  # BASELINE config 4's mechanism: SNP-range shards (four contexts on GPU 0), files concatenated
+        config = config.split("@")[0]
+        extra = ["--devices", "0,0,0,0"]
     gold = _config_golden(config)
     n_ctrl, n_cases, n_snps = CONFIGS[config]
     out = str(tmp_path / config)
-    extra = []
     if "deleterious_yml" in gold:
         (tmp_path / "groups.yml").write_text(gold["deleterious_yml"])
-        extra = ["-p", str(tmp_path / "groups.yml")]
+        extra += ["-p", str(tmp_path / "groups.yml")]
     p = _run_cli(["-s", str(n_ctrl), "-c", str(n_cases), "-x", str(n_snps), "-f", "0.01", "-n", "1", "--rng", "mt19937", "--seed",
                   str(gold["numpy_seed"]), "--outdir", out] + extra)
     assert p.returncode == 0, p.stderr[-3000:]
