@@ -165,12 +165,7 @@ def test_cli_mt19937_continues_the_numpy_stream(oracle, tmp_path):
     numpy.random.seed(86399)
     random.seed(86399)
     tb = pop.sort_snp_table(pop.generate_snp_table(700, min_maf=0.01))
-    yml = os.path.join(REPO, "deleterious.yml")
-    if "deleterious_yml" in gold:
-        yml = out + "groups.yml"
-        with open(yml, "w") as f:
-            f.write(gold["deleterious_yml"])
-    groups = pop.pick_deleterious(tb, yml)
+    groups = pop.pick_deleterious(tb, os.path.join(REPO, "deleterious.yml"))
     pop.build_samples(groups, 22, 30, 0.5, str(tmp_path))
     st = numpy.random.get_state()
     snps = []
