@@ -80,14 +80,15 @@ def synthetic_samples(S, n_rows_table, snp_ids, rs):
 
 
 def kernel_source_hash():
-    """SHA-256 of the row kernels' sources: what a PMC traffic figure has to have been measured on."""
-    import hashlib
+    """Content hash of everything the library is built from (build.source_hash(): all of csrc/ and include/dnaf.h) -- the
+    launch shape lives in dnaf_api.hip and the short-row shapes run rowmix_kernels.hip.h, so a PMC traffic figure has to
+    have been measured on this very build."""
+    import importlib.util
 
-    h = hashlib.sha256()
-    for f in ("rowgen_kernels.hip.h", "rowrun_kernels.hip.h"):
-        with open(os.path.join(ROOT, "dna-factory_amd", "csrc", f), "rb") as fh:
-            h.update(fh.read())
-    return h.hexdigest()[:16]
+    spec = importlib.util.spec_from_file_location("_dnaf_build", os.path.join(ROOT, "dna-factory_amd", "build.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod.source_hash()[:16]
 
 
 def load_traffic(a, S):

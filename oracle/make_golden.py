@@ -278,15 +278,14 @@ def case_full_flow(pf_mod):
     dump("full_flow_120x400", pf.ordered_snps, spec, 20261, lines_mt, lines_ph, extra)
 
 
-def case_config1(pf_mod, name="config1", n_controls=100, n_cases=100, max_snps=100000, yml_text=None):
-    """(With other arguments: BASELINE config 2, `-s 1000 -c 1000 -x 1000000`, about an hour of the reference's worker.)
-    BASELINE config 1 at its stated size through the UNMODIFIED reference: `pop_factory.py -s 100 -c 100 -x 100000
-    -f 0.01 -n 1` = PopulationFactory(num_processes=1, ...).generate_population(100, 100, 0.01, 100000, 6), with the
-    three things a test cannot otherwise fix pinned from outside: the wall clock the reference takes its numpy seed and
-    its ##filedate from (pop_factory.datetime frozen at 12:34:56 -> numpy.random.seed(123456), pop_factory.py:235),
-    python's `random` (seeded with the same number; the reference never seeds it), and Bio.bgzf.BgzfWriter (biopython
-    is not installed: a stand-in that hashes the text it is given -- parity is on the decompressed stream).
-    Only SHA-256 digests and sizes are stored (the VCF body alone is 83 MB)."""
+def run_reference_cli(pf_mod, tag, n_controls, n_cases, max_snps, yml_text=None, num_processes=1, min_freq=0.01,
+                      snps_path=None, deleterious_list_path=None, offset=None):
+    """One run of the UNMODIFIED reference's `main` flow -- PopulationFactory(...).generate_population(...), exactly what
+    pop_factory.py:673-693 does with the parsed flags -- with the three things a test cannot otherwise fix pinned from
+    outside: the wall clock the reference takes its numpy seed and its ##filedate from (pop_factory.datetime frozen at
+    12:34:56 -> numpy.random.seed(123456), pop_factory.py:235), python's `random` (seeded with the same number; the
+    reference never seeds it), and Bio.bgzf.BgzfWriter (biopython is not installed: a stand-in that hashes the text it
+    is given -- parity is on the decompressed stream).  -> (output directory, dict of SHA-256 digests)."""
     import datetime as real_datetime
     import hashlib
 
@@ -323,7 +322,7 @@ def case_config1(pf_mod, name="config1", n_controls=100, n_cases=100, max_snps=1
             return False
 
     seed = 123456
-    tmp = tempfile.mkdtemp(prefix="dnaf_%s_" % name)
+    tmp = tempfile.mkdtemp(prefix="dnaf_%s_" % tag)
     old_dt, old_writer = pf_mod.datetime, pf_mod.bgzf.BgzfWriter
     pf_mod.datetime = FrozenDatetime
     pf_mod.bgzf.BgzfWriter = HashingWriter
@@ -336,9 +335,10 @@ def case_config1(pf_mod, name="config1", n_controls=100, n_cases=100, max_snps=1
         with open(yml, "w") as f:
             f.write(yml_text)
     try:
-        pf = pf_mod.PopulationFactory(num_processes=1, generate_snps=True, male_odds=0.5, deleterious_config=yml,
-                                      output_path=tmp)
-        pf.generate_population(n_controls, n_cases, 0.01, max_snps, 6)
+        pf = pf_mod.PopulationFactory(num_processes=num_processes, generate_snps=True, male_odds=0.5, deleterious_config=yml,
+                                      deleterious_list_path=deleterious_list_path, sample_id_offset=offset,
+                                      snps_path=snps_path, output_path=tmp)
+        pf.generate_population(n_controls, n_cases, min_freq, max_snps, 6)
     finally:
         os.chdir(cwd)
         pf_mod.datetime, pf_mod.bgzf.BgzfWriter = old_dt, old_writer
@@ -348,23 +348,69 @@ def case_config1(pf_mod, name="config1", n_controls=100, n_cases=100, max_snps=1
             data = f.read()
         return {"sha256": hashlib.sha256(data).hexdigest(), "bytes": len(data)}
 
+    flags = "-s %d -c %d" % (n_cases, n_controls)
+    if max_snps is not None:
+        flags += " -x %d" % max_snps
+    flags += " -f %s -n %d" % (min_freq, num_processes)
+    if yml_text is not None:
+        flags += " -p groups.yml"
+    if snps_path:
+        flags += " --snps_file <step 1>/snps.json.gz"
+    if deleterious_list_path:
+        flags += " --deleterious_file <step 1>/deleterious.json"
+    if offset:
+        flags += " --offset %d" % offset
     doc = {
-        "command": "pop_factory.py -s %d -c %d -x %d -f 0.01 -n 1  (reference, unmodified; clock frozen at 12:34:56)" % (n_controls, n_cases, max_snps),
+        "command": "pop_factory.py %s  (reference, unmodified; clock frozen at 12:34:56)" % flags,
         "numpy_seed": seed, "python_random_seed": seed,
         "vcf_without_filedate": {"sha256": HashingWriter.digest, "bytes": HashingWriter.n_bytes, "lines": HashingWriter.n_lines,
                                  "first_body_line_head": HashingWriter.first_body_line},
         "population_fam": sha(os.path.join(tmp, "population.fam")),
         "pop_deleterious_txt": sha(os.path.join(tmp, "pop_deleterious.txt")),
-        "deleterious_json": sha(os.path.join(tmp, "deleterious.json")),
-        "snps_json_decompressed": sha(os.path.join(tmp, "snps.json.gz"), gzip.open),
     }
+    # written only when the run picked / generated them itself (pop_factory.py:246-250)
+    if os.path.exists(os.path.join(tmp, "deleterious.json")):
+        doc["deleterious_json"] = sha(os.path.join(tmp, "deleterious.json"))
+    if os.path.exists(os.path.join(tmp, "snps.json.gz")):
+        doc["snps_json_decompressed"] = sha(os.path.join(tmp, "snps.json.gz"), gzip.open)
     if yml_text is not None:
         doc["deleterious_yml"] = yml_text
-        doc["command"] = doc["command"].replace(" -n 1", " -n 1 -p groups.yml")
+    return tmp, doc
+
+
+def case_config1(pf_mod, name="config1", n_controls=100, n_cases=100, max_snps=100000, yml_text=None, num_processes=1):
+    """BASELINE config 1 at its stated size through the UNMODIFIED reference: `pop_factory.py -s 100 -c 100 -x 100000
+    -f 0.01 -n 1` (run_reference_cli above).  With other arguments: BASELINE config 2 (`-s 1000 -c 1000 -x 1000000`,
+    about an hour of the reference's worker), configs 3 / 5 at 1 % of their SNPs, a run that crosses the reference's
+    2M-SNP chunking line (`chunks_2000001`: two work chunks, the stream restarts, pop_factory.py:402-411), and the
+    reference's DEFAULT worker count (`workers2_*`: -n 2, both forked workers draw the same stream).
+    Only SHA-256 digests and sizes are stored (the VCF body alone is 83 MB)."""
+    _tmp, doc = run_reference_cli(pf_mod, name, n_controls, n_cases, max_snps, yml_text, num_processes)
     path = os.path.join(GOLD, "%s_sha256.json" % name)
     with open(path, "w") as f:
         json.dump(doc, f, indent=1)
     print("wrote %s: %s" % (path, json.dumps(doc["vcf_without_filedate"])))
+
+
+def case_workflow(pf_mod, name="workflow", num_processes=1, n_snps=20000):
+    """The reference README's multi-job workflow (README.md:69-103) through the unmodified reference, three runs:
+      step 1  -s 0 -c 0 -x 20000 -f 0.01            selects SNPs and deleterious SNPs, "empty" VCF (lines without cells)
+      step 2  -s 50 -c 50 --snps_file <1>/snps.json.gz --deleterious_file <1>/deleterious.json
+      step 3  the same with --offset 1000
+    (pop_factory.py:237-250 load paths, :264-272, :515-519 / :613-619 with its string-key quirk SURVEY Q8, :341-383 ids).
+    `num_processes=2` records the same three commands at the reference's default -n (README's literal commands)."""
+    out = {}
+    d1, out["step1"] = run_reference_cli(pf_mod, name + "1", 0, 0, n_snps, num_processes=num_processes)
+    snps, dele = os.path.join(d1, "snps.json.gz"), os.path.join(d1, "deleterious.json")
+    # -x absent, -f at its default 0.005 (pop_factory.py:644-648): neither is used when the SNPs are loaded
+    _d, out["step2"] = run_reference_cli(pf_mod, name + "2", 50, 50, None, num_processes=num_processes, min_freq=0.005,
+                                         snps_path=snps, deleterious_list_path=dele)
+    _d, out["step3"] = run_reference_cli(pf_mod, name + "3", 50, 50, None, num_processes=num_processes, min_freq=0.005,
+                                         snps_path=snps, deleterious_list_path=dele, offset=1000)
+    path = os.path.join(GOLD, "%s_sha256.json" % name)
+    with open(path, "w") as f:
+        json.dump(out, f, indent=1)
+    print("wrote %s: %s" % (path, json.dumps({k: v["vcf_without_filedate"]["sha256"][:12] for k, v in out.items()})))
 
 
 # four deleterious groups for the config-5-shaped run (polygenic stress): different sizes, weights and frequency windows
@@ -404,6 +450,17 @@ def main():
         return
     if "--only-config3-1pct" in sys.argv:  # BASELINE config 3's samples and flow at 1 % of its SNPs (the whole would be 40 h)
         case_config1(pf_mod, "config3_1pct", 10000, 10000, 50000)
+        return
+    if "--only-chunks" in sys.argv:  # 2,000,001 SNPs x 4 samples: two of the reference's work chunks (a few minutes)
+        case_config1(pf_mod, "chunks_2000001", 2, 2, 2000001)
+        return
+    if "--only-workflow" in sys.argv:  # README.md:69-103, at -n 1 and at the reference's default -n 2
+        case_workflow(pf_mod, "workflow", 1)
+        case_workflow(pf_mod, "workflow_n2", 2)
+        return
+    if "--only-workers" in sys.argv:  # the reference's default -n 2 (and -n 3): forked workers share one stream
+        case_config1(pf_mod, "workers2_100x20000", 50, 50, 20000, num_processes=2)
+        case_config1(pf_mod, "workers3_100x20001", 50, 50, 20001, num_processes=3)
         return
     if "--only-long-rows" in sys.argv:  # rows long enough for the line-owning GPU kernel (S >= 2,033), several rows per wave
         case_mixed(pf_mod, "mixed_60x2100", 60, 2100, 424242, numpy.random.RandomState(3))

@@ -276,7 +276,11 @@ def test_two_shards_give_the_same_vcf_and_bed(tmp_path):
 # ---- BASELINE configs 1 and 2 at their stated sizes, against the unmodified reference CLI (tests/golden/config*_sha256.json) ----
 CONFIGS = {"config1": (100, 100, 100000), "config2": (1000, 1000, 1000000),
            "config3_1pct": (10000, 10000, 50000),  # config 3's 20,000 samples and flow at 1 % of its SNPs (all of it: 40 h of the reference)
-           "config5_1pct": (25000, 25000, 10000)}  # config 5's 50,000 samples and four deleterious groups (the fixture holds the YAML)
+           "config5_1pct": (25000, 25000, 10000),  # config 5's 50,000 samples and four deleterious groups (the fixture holds the YAML)
+           # 2,000,001 SNPs: the reference cuts them into two work chunks and its forked workers restart the random stream at
+           # each (pop_factory.py:402-411) -- what it writes for BASELINE configs 3 and 4 (5M / 40M SNPs)
+           "chunks_2000001": (2, 2, 2000001)}
+EXTRA_FLAGS = {"chunks_2000001": ["--compat-chunk-restart"]}
 
 
 def _config_golden(name):
@@ -337,12 +341,21 @@ def test_config_whole_output_directory_equals_the_reference(cli, tmp_path, confi
     gold = _config_golden(config)
     n_ctrl, n_cases, n_snps = CONFIGS[config]
     out = str(tmp_path / config)
+    extra += EXTRA_FLAGS.get(config, [])
     if "deleterious_yml" in gold:
         (tmp_path / "groups.yml").write_text(gold["deleterious_yml"])
         extra += ["-p", str(tmp_path / "groups.yml")]
     p = _run_cli(["-s", str(n_ctrl), "-c", str(n_cases), "-x", str(n_snps), "-f", "0.01", "-n", "1", "--rng", "mt19937", "--seed",
                   str(gold["numpy_seed"]), "--outdir", out] + extra)
     assert p.returncode == 0, p.stderr[-3000:]
+    import hashlib
+
+    _assert_directory_equals(out, gold)
+
+
+def _vcf_digest(out):
+    """What oracle/make_golden.py's stand-in for biopython's writer records: SHA-256 of the decompressed VCF without its
+    ##filedate line, byte and line counts, head of the first body line."""
     import hashlib
 
     h, n_bytes, n_lines, first = hashlib.sha256(), 0, 0, None
@@ -355,14 +368,117 @@ def test_config_whole_output_directory_equals_the_reference(cli, tmp_path, confi
             h.update(line)
             n_bytes += len(line)
             n_lines += 1
-    want = gold["vcf_without_filedate"]
-    assert first == want["first_body_line_head"]
-    assert (n_lines, n_bytes) == (want["lines"], want["bytes"])
-    assert h.hexdigest() == want["sha256"]
-    assert _sha(gzip.open(os.path.join(out, "snps.json.gz"), "rb").read()) == gold["snps_json_decompressed"]
+    return {"sha256": h.hexdigest(), "bytes": n_bytes, "lines": n_lines, "first_body_line_head": first}
+
+
+def _assert_directory_equals(out, gold):
+    """Every file the reference run wrote (the fixture lists them) hashes the same here; files the reference did not
+    write in that mode (snps.json.gz / deleterious.json when they were passed in) must be absent here too."""
+    got, want = _vcf_digest(out), gold["vcf_without_filedate"]
+    assert got["first_body_line_head"] == want["first_body_line_head"]
+    assert (got["lines"], got["bytes"]) == (want["lines"], want["bytes"])
+    assert got["sha256"] == want["sha256"]
+    if "snps_json_decompressed" in gold:
+        assert _sha(gzip.open(os.path.join(out, "snps.json.gz"), "rb").read()) == gold["snps_json_decompressed"]
+    else:
+        assert not os.path.exists(os.path.join(out, "snps.json.gz"))
     for name, key in (("deleterious.json", "deleterious_json"), ("population.fam", "population_fam"),
                       ("pop_deleterious.txt", "pop_deleterious_txt")):
-        assert _sha(open(os.path.join(out, name), "rb").read()) == gold[key], name
+        if key in gold:
+            assert _sha(open(os.path.join(out, name), "rb").read()) == gold[key], name
+        else:
+            assert not os.path.exists(os.path.join(out, name)), name
+
+
+# ---- the reference README's multi-job workflow (README.md:69-103), three runs, against the unmodified reference ----
+def _workflow_commands(base, offset_step3=1000):
+    d1, d2, d3 = (os.path.join(base, d) for d in ("step1", "step2", "step3"))
+    reuse = ["--snps_file", os.path.join(d1, "snps.json.gz"), "--deleterious_file", os.path.join(d1, "deleterious.json")]
+    return [("step1", d1, ["-s", "0", "-c", "0", "-x", "20000", "-f", "0.01"]),
+            ("step2", d2, ["-s", "50", "-c", "50"] + reuse),
+            ("step3", d3, ["-s", "50", "-c", "50", "--offset", str(offset_step3)] + reuse)]
+
+
+@pytest.mark.gpu
+def test_readme_multi_job_workflow_equals_the_reference(cli, tmp_path):
+    """Step 1 `-s 0 -c 0 -x 20000 -f 0.01` (selects SNPs and deleterious SNPs, a VCF of lines without cells), step 2
+    `-s 50 -c 50 --snps_file <1>/snps.json.gz --deleterious_file <1>/deleterious.json`, step 3 the same with `--offset
+    1000`: with `--rng mt19937 --compat-deleterious-file-bug` every output directory is what the unmodified reference
+    wrote for the same commands (tests/golden/workflow_sha256.json; S = 0 through the CLI and the GPU encoder,
+    load_snps_file / load_deleterious pop_factory.py:264-272, :515-519, :613-619, ids with an offset :341-383).
+    Without the compat flag the ids of a loaded deleterious.json are integers, so forcing works: the
+    sample files stay the reference's, the VCF differs in the carriers' cells."""
+    gold = _config_golden("workflow")
+    common = ["-n", "1", "--rng", "mt19937", "--seed", str(gold["step1"]["numpy_seed"])]
+    for step, out, args in _workflow_commands(str(tmp_path)):
+        p = _run_cli(args + common + ["--compat-deleterious-file-bug", "--outdir", out])
+        assert p.returncode == 0, p.stderr[-3000:]
+        _assert_directory_equals(out, gold[step])
+    # default: integer keys
+    step, _out, args = _workflow_commands(str(tmp_path))[1]
+    fixed = str(tmp_path / "step2_forcing")
+    p = _run_cli(args + common + ["--outdir", fixed])
+    assert p.returncode == 0, p.stderr[-3000:]
+    for name, key in (("population.fam", "population_fam"), ("pop_deleterious.txt", "pop_deleterious_txt")):
+        assert _sha(open(os.path.join(fixed, name), "rb").read()) == gold[step][key], name
+    got, want = _vcf_digest(fixed), gold[step]["vcf_without_filedate"]
+    assert (got["lines"], got["bytes"]) == (want["lines"], want["bytes"]) and got["sha256"] != want["sha256"]
+    a = gzip.open(os.path.join(fixed, "population.vcf.gz"), "rt").read().splitlines()
+    b = gzip.open(os.path.join(str(tmp_path), "step2", "population.vcf.gz"), "rt").read().splitlines()
+    carried = {}
+    for line in open(os.path.join(fixed, "pop_deleterious.txt")):
+        parts = line.rstrip("\n").split("\t")
+        carried[parts[0]] = {x for x in parts[2:] if x}
+    iids = a[5].split("\t")[9:]
+    n_forced = 0
+    for la, lb in zip(a[6:], b[6:]):
+        if la == lb:
+            continue
+        fa, fb = la.split("\t"), lb.split("\t")
+        assert fa[:9] == fb[:9]
+        for iid, ca, cb in zip(iids, fa[9:], fb[9:]):
+            if ca != cb:  # only carriers' cells change, and only to the forced genotype (pop_factory.py:495-499)
+                assert fa[2] in carried[iid] and ca in ("1/1", "1"), (fa[2], iid, ca, cb)
+                n_forced += 1
+    assert n_forced > 0
+
+
+def test_workflow_sample_files_equal_the_reference(cli, tmp_path):
+    """Host side of the same three runs, without a GPU: snps.json.gz / deleterious.json written by step 1, read back by
+    steps 2 and 3 (string keys like the reference's from_json, or integers), population.fam and pop_deleterious.txt with
+    and without --offset."""
+    import random
+
+    from dna_factory_amd import population as pop
+
+    gold = _config_golden("workflow")
+    seed = gold["step1"]["numpy_seed"]
+    d1 = str(tmp_path / "s1") + os.path.sep
+    os.makedirs(d1)
+    np.random.seed(seed)
+    random.seed(gold["step1"]["python_random_seed"])
+    tb = pop.sort_snp_table(pop.generate_snp_table(20000, min_maf=0.01))
+    pop.write_snps_file(tb, d1 + "snps.json.gz")
+    groups = pop.pick_deleterious(tb, os.path.join(REPO, "deleterious.yml"))
+    pop.write_deleterious_json(groups, d1 + "deleterious.json")
+    st = pop.build_samples(groups, 0, 0, 0.5, d1, offset=0)
+    assert len(st) == 0
+    for name, key in (("deleterious.json", "deleterious_json"), ("population.fam", "population_fam"),
+                      ("pop_deleterious.txt", "pop_deleterious_txt")):
+        assert _sha(open(d1 + name, "rb").read()) == gold["step1"][key], name
+    assert _sha(gzip.open(d1 + "snps.json.gz", "rb").read()) == gold["step1"]["snps_json_decompressed"]
+    for step, offset in (("step2", 0), ("step3", 1000)):
+        for int_keys in (False, True):
+            d = str(tmp_path / (step + str(int_keys))) + os.path.sep
+            os.makedirs(d)
+            np.random.seed(seed)
+            random.seed(gold[step]["python_random_seed"])
+            tb2 = pop.sort_snp_table(pop.load_snps_file(d1 + "snps.json.gz"))
+            assert len(tb2) == 20000
+            g2 = pop.load_deleterious_json(d1 + "deleterious.json", int_keys=int_keys)
+            pop.build_samples(g2, 50, 50, 0.5, d, offset=offset)
+            for name, key in (("population.fam", "population_fam"), ("pop_deleterious.txt", "pop_deleterious_txt")):
+                assert _sha(open(d + name, "rb").read()) == gold[step][key], (step, int_keys, name)
 
 
 def test_cli_rejects_an_empty_device_list(tmp_path):
