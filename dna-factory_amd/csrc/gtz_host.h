@@ -24,11 +24,18 @@ constexpr uint32_t GTZ_NSYM = 320;      // histogram layout per class: [0,286) l
 constexpr uint32_t GTZ_DIST0 = 286;
 constexpr uint32_t GTZ_HDR_WORDS = 64;  // header bits of a class (<= 2048)
 constexpr uint32_t GTZ_CHUNK_CELLS = 64; // cells (= 256 text bytes) tokenised by one thread
+constexpr uint32_t GTZ_GAP_STRIDE = 264; // entries per half of the gap table (gap lengths 0..256)
 
 // Entries are (bit pattern << 5) | bit count, patterns in LSB-first stream order.
 struct GtzClassTables {
     uint32_t lit[256];   // literal byte -> code
     uint32_t len[256];   // match length L (index L - 3) -> length code + extra bits (<= 20 bits)
+    // gap[h][L]: the L bytes between two events of a chunk (gtz_tokens.hip.h), every one repeating the byte four back:
+    // L >= 3 one match (length code + extra bits + the code of distance 4), L = 1 the separator's literal -- '/' in
+    // half 0 (the gap begins behind allele a), '\t' in half 1 (behind allele b) --, L = 0 nothing.  At most 27 bits.
+    uint32_t gap[2 * GTZ_GAP_STRIDE];
+    uint32_t len4[GTZ_CHUNK_CELLS + 8]; // LZ77 match of f cells (4 f bytes) -> length code + extra bits
+    uint32_t unit_ok;    // 1: a gap code and the literal '0' / '1' behind it fit 32 bits together (what the kernel emits as one unit)
     uint32_t dist[32];   // distance symbol -> code (extra bits are appended by the kernel)
     uint32_t eob;
     uint32_t hdr_nbits;
@@ -98,6 +105,21 @@ inline void gtz_build_class(const uint64_t* litlen_hist, const uint64_t* dist_hi
     }
     memset(t->dist, 0, sizeof t->dist);
     for (uint32_t s = 0; s < 30; ++s) t->dist[s] = (dc[s] << 5) | dl[s];
+    memset(t->gap, 0, sizeof t->gap);
+    memset(t->len4, 0, sizeof t->len4);
+    uint32_t widest = 0;
+    for (uint32_t L = 3; L <= 256; ++L) {
+        const uint32_t le = t->len[L - 3], ln = le & 31u, dn = dl[3];
+        const uint32_t n = ln + dn;
+        widest = n > widest ? n : widest;
+        const uint32_t e = n <= 27 ? (((le >> 5) | (dc[3] << ln)) << 5) | n : 0u;
+        t->gap[L] = t->gap[GTZ_GAP_STRIDE + L] = e;
+    }
+    t->gap[1] = t->lit[(unsigned char)'/'];
+    t->gap[GTZ_GAP_STRIDE + 1] = t->lit[(unsigned char)'\t'];
+    for (uint32_t f = 1; f <= GTZ_CHUNK_CELLS; ++f) t->len4[f] = t->len[4 * f - 3];
+    const uint32_t lit_w = std::max(std::max(ll[(unsigned char)'0'], ll[(unsigned char)'1']), std::max(ll[(unsigned char)'/'], ll[(unsigned char)'\t']));
+    t->unit_ok = widest <= 27 && widest + lit_w <= 32 ? 1u : 0u;
     t->len_nb[0] = t->len_nb[1] = t->dist_nb[0] = t->dist_nb[1] = 0;
     for (uint32_t s = 0; s < 29; ++s) t->len_nb[s >> 4] |= (uint64_t)ll[257 + s] << (4 * (s & 15));
     for (uint32_t s = 0; s < 30; ++s) t->dist_nb[s >> 4] |= (uint64_t)dl[s] << (4 * (s & 15));

@@ -93,7 +93,7 @@ struct GtzShared {
     };
     uint32_t cells[GTZ_CELL_WORDS + 4];
     uint32_t far[GTZ_MAX_CHUNKS * GTZ_MAX_FAR]; // cell in chunk | cells << 6 | distance in bytes << 13
-    uint32_t codes[256 + 256 + 32];             // lit, len, dist code tables; the symbol histogram in gtz_encode<true>
+    uint32_t codes[256 + 2 * GTZ_GAP_STRIDE + GTZ_CHUNK_CELLS + 8 + 32]; // lit, gap, len4, dist code tables; the symbol histogram in gtz_encode<true>
     uint32_t crc_table[256];
     uint32_t crc_base[GTZ_CHUNK_CELLS + 1];
     uint32_t crc_unit_a[2 * GTZ_CHUNK_CELLS]; // first allele's units, then (crc_unit_b) the second allele's
@@ -112,11 +112,12 @@ struct GtzShared {
     uint32_t scratch[3 * GTZ_WAVES];
     uint32_t nr, n_items, ok, klass;
     __device__ __forceinline__ uint32_t* lit() { return codes; }
-    __device__ __forceinline__ uint32_t* len() { return codes + 256; }
-    __device__ __forceinline__ uint32_t* dist() { return codes + 512; }
+    __device__ __forceinline__ uint32_t* gap() { return codes + 256; }
+    __device__ __forceinline__ uint32_t* len4() { return codes + 256 + 2 * GTZ_GAP_STRIDE; }
+    __device__ __forceinline__ uint32_t* dist() { return codes + 256 + 2 * GTZ_GAP_STRIDE + GTZ_CHUNK_CELLS + 8; }
     __device__ __forceinline__ uint32_t* hist() { return codes; }
 };
-static_assert(GTZ_NSYM <= 544, "the histogram reuses the code tables");
+static_assert(GTZ_NSYM <= 256 + 2 * GTZ_GAP_STRIDE, "the histogram reuses the code tables");
 
 // 16 cells of the 2-bit stream starting at g
 __device__ __forceinline__ uint32_t gtz_window(const uint32_t* cells, uint32_t g)
@@ -206,24 +207,11 @@ struct GtzCount {
     GtzShared* s;
     uint32_t bits;
     __device__ __forceinline__ void lit(uint32_t b) { bits += s->lit()[b] & 31u; }
-    __device__ __forceinline__ void match(uint32_t L, uint32_t d)
-    {
-        uint32_t sym, eb, ev;
-        gtz_dist_symbol(d, &sym, &eb, &ev);
-        bits += (s->len()[L - 3u] & 31u) + (s->dist()[sym] & 31u) + eb;
-    }
 };
 
 struct GtzHist {
     GtzShared* s;
     __device__ __forceinline__ void lit(uint32_t b) { atomicAdd(&s->hist()[b], 1u); }
-    __device__ __forceinline__ void match(uint32_t L, uint32_t d)
-    {
-        uint32_t sym, eb, ev;
-        gtz_dist_symbol(d, &sym, &eb, &ev);
-        atomicAdd(&s->hist()[gtz_len_symbol(L)], 1u);
-        atomicAdd(&s->hist()[GTZ_DIST0 + sym], 1u);
-    }
 };
 
 struct GtzEmit {
@@ -243,14 +231,6 @@ struct GtzEmit {
     }
     __device__ __forceinline__ void entry(uint32_t e) { put(e >> 5, e & 31u); }
     __device__ __forceinline__ void lit(uint32_t b) { entry(s->lit()[b]); }
-    __device__ __forceinline__ void match(uint32_t L, uint32_t d)
-    {
-        uint32_t sym, eb, ev;
-        gtz_dist_symbol(d, &sym, &eb, &ev);
-        entry(s->len()[L - 3u]);
-        entry(s->dist()[sym]);
-        if (eb) put(ev, eb);
-    }
     __device__ __forceinline__ void flush()
     {
         if (nacc) atomicOr(&s->image[word], (uint32_t)acc);
@@ -322,7 +302,7 @@ __global__ __launch_bounds__(GTZ_THREADS) void gtz_encode(const GtzParams p)
     }
     __syncthreads();
     if (tid == 0) {
-        uint32_t nr = 0, ok = 1;
+        uint32_t nr = 0, ok = HIST ? 1u : p.tables->cls[0].unit_ok; // (every class is built alike: one flag says it for all)
         while (nr <= GTZ_MAX_ROWS && s->off[nr] != 0x7FFFFFFF) ++nr;
         if (nr > GTZ_MAX_ROWS || p.S < 2u) ok = 0;
         uint32_t items = 0, chunks = 0, words = 0, best_cells = 0, best_row = 0;
@@ -388,7 +368,8 @@ __global__ __launch_bounds__(GTZ_THREADS) void gtz_encode(const GtzParams p)
         for (uint32_t t = tid; t < GTZ_NSYM; t += GTZ_THREADS) s->hist()[t] = 0;
     } else {
         s->lit()[tid] = ct->lit[tid];
-        s->len()[tid] = ct->len[tid];
+        for (uint32_t t = tid; t < 2 * GTZ_GAP_STRIDE; t += GTZ_THREADS) s->gap()[t] = ct->gap[t];
+        if (tid < GTZ_CHUNK_CELLS + 8) s->len4()[tid] = ct->len4[tid];
         if (tid < 32) s->dist()[tid] = ct->dist[tid];
         s->crc_table[tid] = p.tables->crc_table[tid];
         if (tid <= GTZ_CHUNK_CELLS) s->crc_base[tid] = p.tables->crc_base[tid];
@@ -460,7 +441,7 @@ __global__ __launch_bounds__(GTZ_THREADS) void gtz_encode(const GtzParams p)
     bool it_span[2];
     GtzChunk ch[2];
     const uint32_t* it_far[2];
-    GtzTokens tks[2];
+    GtzEvents evs[2];
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
         const uint32_t it = tid + (uint32_t)u * GTZ_THREADS;
@@ -498,15 +479,14 @@ __global__ __launch_bounds__(GTZ_THREADS) void gtz_encode(const GtzParams p)
             uint32_t* farlist = s->far + (s->chunk_base[i] + local - 1u) * GTZ_MAX_FAR;
             it_far[u] = farlist;
             ch[u] = gtz_load_chunk(s, i, c64, k0, k1);
-            if (DNAF_GTZ_EXP == 1) farlist[0] = 0; else gtz_find_matches(s, i, c64, ch[u], farlist);
-            tks[u] = gtz_tokens(ch[u], farlist);
-            const GtzTokens& tk = tks[u];
+            evs[u] = gtz_find_matches(s, i, c64, ch[u], farlist, DNAF_GTZ_EXP != 1);
             if (HIST) {
                 GtzSymbolCount hs{s->hist()};
-                gtz_emit_tokens(ch[u], tk, farlist, hs);
+                gtz_walk(ch[u], evs[u], farlist, hs);
             } else {
-                GtzBitCount cnt{lit_bits, s->len(), s->dist(), 0};
-                bits[u] = DNAF_GTZ_EXP == 3 ? 150u : gtz_count_bits(ch[u], tk, farlist, cnt);
+                GtzBitCount cnt{s->gap(), s->len4(), s->dist(), lit_bits, 0};
+                if (DNAF_GTZ_EXP != 3) gtz_walk(ch[u], evs[u], farlist, cnt);
+                bits[u] = DNAF_GTZ_EXP == 3 ? 150u : cnt.bits;
                 // CRC of the chunk's bytes from its cells: base pattern + one unit per '1' allele.  Only the set bits of the
                 // chunk's code words are visited (a tenth to a third of the 128 alleles), not every cell.
                 const uint32_t n = k1 - k0;
@@ -611,9 +591,8 @@ __global__ __launch_bounds__(GTZ_THREADS) void gtz_encode(const GtzParams p)
             for (int32_t pos = s->span_lo[i]; pos < s->span_hi[i]; ++pos) e.lit(gtz_text_byte(p, s, m_row, i, pos));
             e.flush();
         } else {
-            GtzBitEmit e{s->image, s->len(), s->dist(), {s->lit()['0'], s->lit()['1'], s->lit()['/'], s->lit()['\t']}, 0, start & 31u, start >> 5};
-            if (DNAF_GTZ_EXP != 2) gtz_emit_tokens(ch[u], tks[u], it_far[u], e);
-            e.flush();
+            GtzBitEmit e{s->image, s->gap(), s->len4(), s->dist(), {s->lit()['0'], s->lit()['1'], s->lit()['/'], s->lit()['\t']}, start};
+            if (DNAF_GTZ_EXP != 2) gtz_walk(ch[u], evs[u], it_far[u], e);
         }
     }
     if (tid == 0) {

@@ -1,103 +1,175 @@
-// gtz_tokens.hip.h -- search and tokenisation of one 64-cell chunk for the genotype-domain BGZF encoder,
-// written so that the lanes of a wave stay together: the chunk's state is a handful of bit masks in
-// registers, loops run over events (breaks, tokens) rather than cells, and literals need no LDS access.
+// gtz_tokens.hip.h -- search and tokenisation of one 64-cell chunk for the genotype-domain BGZF encoder.
 //
-// Byte view of a chunk: 256 text bytes = 4 words of 64 bits, bit i of word w = byte 64 w + i.  Byte i of a
-// cell-aligned word belongs to cell i >> 2; bytes 0 and 2 of a cell are the alleles, 1 is '/', 3 is '\t'.
+// A chunk is 64 cells = 128 alleles = 256 text bytes "a/b\t".  Its state is a handful of bit masks in registers,
+// ALLELE space: bit 2j of a 128-bit mask is allele a of cell j (text byte 4j), bit 2j + 1 allele b (byte 4j + 2).
+// The cell codes (lo:hi) are the allele values in that very layout, and x = code ^ previous cell's code marks the
+// alleles whose byte differs from the byte four back ("breaks").  Every other byte of the text -- '/' and '\t', and
+// the alleles that do not break -- equals the byte four before it.
+//
+// Token stream of a chunk (deflate symbols): LZ77 matches found by the search ("far": whole cells copied from an
+// earlier place of the member), and between them literals for the breaking alleles and, for the bytes from one
+// event to the next (a "gap": every byte of it repeats the byte four back), one match at distance 4 when the gap
+// has three bytes or more, literals when it has one or two.  So the stream is a list of EVENTS -- breaking alleles
+// and far matches, in byte order -- and each event emits [gap before it][its own symbol]; the walk visits events,
+// not bytes or tokens: one table read gives the gap's code (length code + extra bits + the code of distance 4, or
+// the separator's literal), and gap and literal leave as ONE unit of at most 32 bits.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
 namespace dnaf {
 
-// spread the 32 bits of v to the even... every 2-bit group of v to the low half of a nibble of the result
-__device__ __forceinline__ uint64_t gtz_spread_pairs(uint32_t v)
-{
-    uint64_t t = v;
-    t = (t | (t << 16)) & 0x0000FFFF0000FFFFull;
-    t = (t | (t << 8)) & 0x00FF00FF00FF00FFull;
-    t = (t | (t << 4)) & 0x0F0F0F0F0F0F0F0Full;
-    t = (t | (t << 2)) & 0x3333333333333333ull;
-    return t;
-}
-
-// bits [lo, hi) of a 256-bit mask, word w of it
-__device__ __forceinline__ uint64_t gtz_range_word(uint32_t lo, uint32_t hi, uint32_t w)
-{
-    const uint32_t base = 64u * w;
-    const uint32_t a = lo > base ? lo - base : 0u, b = hi > base ? hi - base : 0u;
-    return gtz_low_mask(min(b, 64u)) & ~gtz_low_mask(min(a, 64u));
-}
-
-// Token masks of a chunk.  run3: bytes inside distance-4 matches (runs of >= 3 repeating bytes outside the
-// LZ77 matches); plain: bytes that are tokens of their own or inside a distance-4 match (valid and not
-// covered by an LZ77 match); far: first byte of each recorded LZ77 match.
-struct GtzTokens {
-    uint64_t run3[4], plain[4], far[4];
-    uint32_t ext[4]; // ext[w]: bytes by which a distance-4 run that reaches the end of word w goes on in the words after it
+// 128-bit allele-space mask
+struct GtzMask {
+    uint64_t lo, hi;
 };
 
-__device__ __forceinline__ GtzTokens gtz_tokens(const GtzChunk& c, const uint32_t* farlist)
+// bits [a, b) of a 128-bit mask
+__device__ __forceinline__ GtzMask gtz_range(uint32_t a, uint32_t b)
 {
-    GtzTokens t;
-    uint64_t M[4];
-    const uint32_t lo = 4u * c.j0, hi = 4u * c.j1;
-    const uint32_t xs[4] = {(uint32_t)c.xlo, (uint32_t)(c.xlo >> 32), (uint32_t)c.xhi, (uint32_t)(c.xhi >> 32)};
-#pragma unroll
-    for (int w = 0; w < 4; ++w) {
-        const uint64_t s = gtz_spread_pairs(xs[w]);                                     // [xa, xb, 0, 0] per cell
-        const uint64_t brk = (s & 0x1111111111111111ull) | ((s & 0x2222222222222222ull) << 1); // allele bytes that differ
-        t.plain[w] = gtz_range_word(lo, hi, (uint32_t)w);
-        M[w] = ~brk & t.plain[w];
-        t.far[w] = 0;
-    }
-    if (c.head) { // the region's first cell: its '/' and '\t' have nothing to repeat either
-#pragma unroll
-        for (int w = 0; w < 4; ++w) M[w] &= ~gtz_range_word(lo, lo + 4u, (uint32_t)w);
-    }
-    for (uint32_t n = 0; n < GTZ_MAX_FAR; ++n) {
-        const uint32_t e = farlist[n];
-        if (!(e >> 6)) break;
-        const uint32_t a = lo + 4u * (e & 63u), b = a + 4u * ((e >> 6) & 127u);
-#pragma unroll
-        for (int w = 0; w < 4; ++w) {
-            const uint64_t r = gtz_range_word(a, b, (uint32_t)w);
-            t.plain[w] &= ~r;
-            M[w] &= ~r;
-            t.far[w] |= gtz_range_word(a, a + 1u, (uint32_t)w);
-        }
-    }
-#pragma unroll
-    for (int w = 0; w < 4; ++w) {
-        const uint64_t below = w ? M[w - 1] : 0ull, above = w < 3 ? M[w + 1] : 0ull;
-        const uint64_t up = (M[w] << 1) | (below >> 63), up2 = (M[w] << 2) | (below >> 62);
-        const uint64_t dn = (M[w] >> 1) | (above << 63), dn2 = (M[w] >> 2) | (above << 62);
-        t.run3[w] = M[w] & ((up & up2) | (up & dn) | (dn & dn2));
-    }
-    // worked out once here, not at every match of the two token walks
-    t.ext[3] = 0;
-#pragma unroll
-    for (int w = 2; w >= 0; --w) {
-        const uint32_t more = ~t.run3[w + 1] ? (uint32_t)__builtin_ctzll(~t.run3[w + 1]) : 64u;
-        t.ext[w] = more + (more == 64u ? t.ext[w + 1] : 0u);
-    }
-    return t;
+    GtzMask m;
+    m.lo = gtz_low_mask(min(b, 64u)) & ~gtz_low_mask(min(a, 64u));
+    m.hi = gtz_low_mask(b > 64u ? b - 64u : 0u) & ~gtz_low_mask(a > 64u ? a - 64u : 0u);
+    return m;
 }
 
-// Sinks receive literals as a kind (0 '0', 1 '1', 2 '/', 3 '\t') and matches as (length, distance in bytes).
+// What the search leaves for the walks: the far matches' first alleles and the alleles that are events of their
+// own.  The far list (LDS) holds (first cell - j0) | cells << 6 | distance in bytes << 13, in order.
+struct GtzEvents {
+    GtzMask ev;  // events: breaking alleles outside far matches, first alleles of far matches, forced literals
+    GtzMask far; // subset: first allele of each far match
+};
+
+
+// LZ77 matches of one chunk (see gtz_kernels.hip.h) and the chunk's event masks.  Lanes step from break to break
+// together; a break is only looked up when the 16 cells from it hold at least GTZ_MIN_BREAKS differing alleles.
+__device__ __forceinline__ GtzEvents gtz_find_matches(GtzShared* s, uint32_t i, uint32_t c64, const GtzChunk& c, uint32_t* farlist, bool search)
+{
+    GtzEvents E;
+    const GtzMask valid = gtz_range(2u * c.j0, 2u * c.j1);
+    E.ev.lo = c.xlo & valid.lo;
+    E.ev.hi = c.xhi & valid.hi;
+    E.far.lo = E.far.hi = 0;
+    uint64_t ends_lo = 0, ends_hi = 0; // bit 2s for every cell s at which a far match ends
+    uint32_t nfar = 0;
+    if (search && c.j1 >= GTZ_KEY_CELLS + c.j0) {
+        const uint32_t gbase = 16u * s->gw[i] - 16u * s->kw0[i] + 64u * c64; // g of the chunk's cell 0
+        const uint32_t grow = 16u * s->gw[i];                                // first g of this row
+        const uint32_t gmin = grow + (s->kb[i] & 15u);                       // first g of this row that lies in the member
+        const int32_t cs = s->cs[i];
+        const uint64_t blo = (c.xlo | (c.xlo >> 1)) & 0x5555555555555555ull;
+        const uint64_t bhi = (c.xhi | (c.xhi >> 1)) & 0x5555555555555555ull;
+        const uint32_t last = c.j1 - GTZ_KEY_CELLS; // last cell a match can start at
+        uint32_t pos = c.j0;
+        for (;;) {
+            const uint32_t j = gtz_next_break(blo, bhi, pos);
+            if (j > last || nfar >= GTZ_MAX_FAR) break;
+            // alleles that differ from the cell before, in the 16 cells from j
+            const uint32_t xw = j < 32u ? (uint32_t)((c.xlo >> (2u * j)) | (j ? c.xhi << (64u - 2u * j) : 0ull)) : (uint32_t)(c.xhi >> (2u * j - 64u));
+            if ((uint32_t)__builtin_popcount(xw) < GTZ_MIN_BREAKS) { pos = j + 1u; continue; }
+            const uint32_t g = gbase + j;
+            const uint32_t dw = c.window(j);
+            const uint32_t key = dw & (GTZ_KEYS - 1u);
+            const uint32_t q = min(g >> GTZ_SEG_SHIFT, GTZ_SEGS - 1u);
+            // candidates: earliest in this quarter, latest / earliest in the one before, latest two back
+            uint32_t cand[GTZ_CANDS];
+            cand[0] = s->tab16[(2u * q) * GTZ_KEYS + key]; // 0xFFFF (none) is never below g
+            cand[1] = q ? (uint32_t)s->tab16[(2u * (q - 1u) + 1u) * GTZ_KEYS + key] - 1u : 0xFFFFFFFFu;
+            if (GTZ_CANDS > 2) cand[2] = q ? (uint32_t)s->tab16[(2u * (q - 1u)) * GTZ_KEYS + key] : 0xFFFFFFFFu;
+            if (GTZ_CANDS > 3) cand[3] = q > 1u ? (uint32_t)s->tab16[(2u * (q - 2u) + 1u) * GTZ_KEYS + key] - 1u : 0xFFFFFFFFu;
+            const uint32_t room = c.j1 - j;
+            bool ok[GTZ_CANDS], other_row = false;
+            uint32_t sg[GTZ_CANDS], n[GTZ_CANDS], lim[GTZ_CANDS], d[GTZ_CANDS];
+#pragma unroll
+            for (int t = 0; t < (int)GTZ_CANDS; ++t) {
+                ok[t] = cand[t] < g;
+                if (t == 2 && ok[2] && cand[2] == cand[1]) ok[2] = false; // one occurrence in that quarter: same position twice
+                sg[t] = ok[t] ? cand[t] : g; // a disabled candidate reads its own position
+                other_row |= ok[t] && sg[t] < gmin;
+            }
+#pragma unroll
+            for (int t = 0; t < (int)GTZ_CANDS; ++t) {
+                const uint32_t xw0 = gtz_window(s->cells, sg[t]) ^ dw;
+                n[t] = xw0 ? (uint32_t)__builtin_ctz(xw0) >> 1 : 16u;
+                lim[t] = room;
+                d[t] = 4u * (g - sg[t]);
+            }
+            if (other_row) { // a source in an earlier row of the member: its own byte distance and end
+#pragma unroll
+                for (int t = 0; t < (int)GTZ_CANDS; ++t) {
+                    if (!ok[t] || sg[t] >= gmin) continue;
+                    uint32_t r = i;
+                    while (r && 16u * s->gw[r] > sg[t]) --r;
+                    const uint32_t ks = sg[t] - 16u * s->gw[r] + 16u * s->kw0[r];
+                    // the source must lie in the member's part of that row: cells [kb, ke)
+                    if (r == i || ks < s->kb[r] || ks >= s->ke[r]) { ok[t] = false; continue; }
+                    d[t] = (uint32_t)(cs + 4 * (int32_t)(64u * c64 + j) - (s->cs[r] + 4 * (int32_t)ks));
+                    lim[t] = min(room, s->ke[r] - ks);
+                }
+            }
+            uint32_t f = 0, dbytes = 0;
+#pragma unroll
+            for (int t = 0; t < (int)GTZ_CANDS; ++t) {
+                // longer than one window: keep comparing (rare except in sparse rows)
+                if (ok[t] && n[t] == 16u)
+                    while (n[t] < lim[t]) {
+                        const uint32_t x = c.window(j + n[t]) ^ gtz_window(s->cells, sg[t] + n[t]);
+                        if (x) { n[t] += (uint32_t)__builtin_ctz(x) >> 1; break; }
+                        n[t] += 16u;
+                    }
+                const uint32_t nt = (ok[t] && d[t] <= 32768u) ? min(n[t], lim[t]) : 0u;
+                if (nt > f || (nt == f && nt && d[t] < dbytes)) { f = nt; dbytes = d[t]; } // ties: the nearer one
+            }
+            bool take = f >= GTZ_KEY_CELLS;
+            if (take) {
+                const GtzMask m = gtz_range(2u * j, 2u * (j + f));
+                take = (uint32_t)(__builtin_popcountll(c.xlo & m.lo) + __builtin_popcountll(c.xhi & m.hi)) >= GTZ_MIN_BREAKS;
+                if (take) {
+                    farlist[nfar++] = (j - c.j0) | (f << 6) | (dbytes << 13);
+                    E.ev.lo &= ~m.lo;
+                    E.ev.hi &= ~m.hi;
+                    if (j < 32u) E.far.lo |= 1ull << (2u * j); else E.far.hi |= 1ull << (2u * j - 64u);
+                    const uint32_t e = j + f;
+                    if (e < 32u) ends_lo |= 1ull << (2u * e); else if (e < 64u) ends_hi |= 1ull << (2u * e - 64u);
+                }
+            }
+            pos = take ? j + f : j + 1u;
+        }
+    }
+    if (nfar < GTZ_MAX_FAR) farlist[nfar] = 0; // terminator: a recorded match has cells != 0
+    // forced literals: allele a at the start of a run that allele b of the same cell cuts to two bytes
+    uint64_t starts_lo = ends_lo, starts_hi = ends_hi;
+    {
+        const uint32_t s0 = c.head ? c.j0 + 1u : c.j0; // (a far match at the head cell has cleared that cell's events: harmless)
+        if (s0 < 32u) starts_lo |= 1ull << (2u * s0); else if (s0 < 64u) starts_hi |= 1ull << (2u * s0 - 64u);
+    }
+    E.ev.lo |= (E.ev.lo >> 1) & starts_lo & valid.lo;
+    E.ev.hi |= (E.ev.hi >> 1) & starts_hi & valid.hi;
+    E.ev.lo |= E.far.lo;
+    E.ev.hi |= E.far.hi;
+    return E;
+}
+
+// ---- sinks of the walk ----
+// gap(L, at): the L bytes from chunk byte `at` up to the next event all repeat the byte four back.  L is 0, 1
+// ('/' when at & 3 == 1, '\t' when at & 3 == 3) or >= 3 (one match at distance 4).
+// lit(kind): 0 '0', 1 '1', 2 '/', 3 '\t'.   far(L, d): LZ77 match of L bytes at distance d.
+
 struct GtzBitCount {
-    uint32_t lit_bits;     // 4 x 8 bits: code length of each literal kind
-    const uint32_t* len;   // LDS: match length -> code + extra bits, total bit count in the low 5 bits
-    const uint32_t* dist;  // LDS: distance symbol -> code, its length in the low 5 bits
+    const uint32_t* gap;   // LDS [2][GTZ_GAP_STRIDE]: gap length -> code, bit count in the low 5 bits
+    const uint32_t* len4;  // LDS: far match of f cells -> length code + extra bits
+    const uint32_t* dist;  // LDS: distance symbol -> code
+    uint32_t lit_n;        // 4 x 8 bits: code length of each literal kind
     uint32_t bits;
-    __device__ __forceinline__ void lit(uint32_t kind) { bits += (lit_bits >> (8u * kind)) & 0xFFu; }
-    // one table read per match (the distance symbol of the distance-4 matches folds to a constant at the call site);
-    // working the length symbol out in registers instead cost 20 instructions per match
-    __device__ __forceinline__ void match(uint32_t L, uint32_t d)
+    __device__ __forceinline__ uint32_t gap_entry(uint32_t L, uint32_t at) const { return gap[L + (at & 2u) * (GTZ_GAP_STRIDE / 2u)]; }
+    __device__ __forceinline__ void gap_lit(uint32_t L, uint32_t at, uint32_t value) { bits += (gap_entry(L, at) & 31u) + ((lit_n >> (8u * value)) & 0xFFu); }
+    __device__ __forceinline__ void gap_only(uint32_t L, uint32_t at) { bits += gap_entry(L, at) & 31u; }
+    __device__ __forceinline__ void lit(uint32_t kind) { bits += (lit_n >> (8u * kind)) & 0xFFu; }
+    __device__ __forceinline__ void far(uint32_t f, uint32_t d)
     {
         uint32_t sym, eb, ev;
         gtz_dist_symbol(d, &sym, &eb, &ev);
-        bits += (len[L - 3u] & 31u) + (dist[sym] & 31u) + eb;
+        bits += (len4[f] & 31u) + (dist[sym] & 31u) + eb;
     }
 };
 
@@ -108,205 +180,102 @@ struct GtzSymbolCount {
         const uint32_t b = kind == 0u ? '0' : kind == 1u ? '1' : kind == 2u ? '/' : '\t';
         atomicAdd(&hist[b], 1u);
     }
-    __device__ __forceinline__ void match(uint32_t L, uint32_t d)
+    __device__ __forceinline__ void gap_only(uint32_t L, uint32_t at)
+    {
+        if (L >= 3u) { atomicAdd(&hist[gtz_len_symbol(L)], 1u); atomicAdd(&hist[GTZ_DIST0 + 3u], 1u); }
+        else if (L == 1u) lit((at & 2u) ? 3u : 2u);
+    }
+    __device__ __forceinline__ void gap_lit(uint32_t L, uint32_t at, uint32_t value) { gap_only(L, at); lit(value); }
+    __device__ __forceinline__ void far(uint32_t f, uint32_t d)
     {
         uint32_t sym, eb, ev;
         gtz_dist_symbol(d, &sym, &eb, &ev);
-        atomicAdd(&hist[gtz_len_symbol(L)], 1u);
+        atomicAdd(&hist[gtz_len_symbol(4u * f)], 1u);
         atomicAdd(&hist[GTZ_DIST0 + sym], 1u);
     }
 };
 
 struct GtzBitEmit {
     uint32_t* image;       // LDS bit buffer (zero-initialised), written with atomic OR
-    const uint32_t* len;   // LDS: match length -> code + extra bits
-    const uint32_t* dist;  // LDS: distance symbol -> code
-    uint32_t lit_entry[4]; // the four literal kinds' codes
-    uint64_t acc;
-    uint32_t nacc, word;
+    const uint32_t* gap;
+    const uint32_t* len4;
+    const uint32_t* dist;
+    uint32_t lit_entry[4]; // the four literal kinds' codes, (bits << 5) | count
+    uint32_t pos;          // bit position in the image
+    // v has n <= 32 bits
     __device__ __forceinline__ void put(uint32_t v, uint32_t n)
     {
-        acc |= (uint64_t)v << nacc;
-        nacc += n;
-        if (nacc >= 32u) {
-            atomicOr(&image[word], (uint32_t)acc);
-            ++word;
-            acc >>= 32;
-            nacc -= 32u;
-        }
+        const uint64_t w = (uint64_t)v << (pos & 31u);
+        uint32_t* at = image + (pos >> 5);
+        atomicOr(at, (uint32_t)w);
+        atomicOr(at + 1, (uint32_t)(w >> 32));
+        pos += n;
     }
     __device__ __forceinline__ void entry(uint32_t e) { put(e >> 5, e & 31u); }
+    __device__ __forceinline__ uint32_t gap_entry(uint32_t L, uint32_t at) const { return gap[L + (at & 2u) * (GTZ_GAP_STRIDE / 2u)]; }
     __device__ __forceinline__ void lit(uint32_t kind)
     {
-        const uint32_t e = kind == 0u ? lit_entry[0] : kind == 1u ? lit_entry[1] : kind == 2u ? lit_entry[2] : lit_entry[3];
-        entry(e);
+        entry(kind == 0u ? lit_entry[0] : kind == 1u ? lit_entry[1] : kind == 2u ? lit_entry[2] : lit_entry[3]);
     }
-    __device__ __forceinline__ void match(uint32_t L, uint32_t d)
+    // gap and literal as one unit: the host guarantees that together they have at most 32 bits (GtzClassTables::unit_ok)
+    __device__ __forceinline__ void gap_lit(uint32_t L, uint32_t at, uint32_t value)
+    {
+        const uint32_t g = gap_entry(L, at), l = value ? lit_entry[1] : lit_entry[0];
+        const uint32_t gn = g & 31u;
+        put((g >> 5) | ((l >> 5) << gn), gn + (l & 31u));
+    }
+    __device__ __forceinline__ void gap_only(uint32_t L, uint32_t at) { entry(gap_entry(L, at)); }
+    __device__ __forceinline__ void far(uint32_t f, uint32_t d)
     {
         uint32_t sym, eb, ev;
         gtz_dist_symbol(d, &sym, &eb, &ev);
-        const uint32_t le = len[L - 3u], de = dist[sym];
-        entry(le);
-        entry(de);
-        if (eb) put(ev, eb);
-    }
-    __device__ __forceinline__ void flush()
-    {
-        if (nacc) atomicOr(&image[word], (uint32_t)acc);
+        entry(len4[f]);
+        const uint32_t de = dist[sym], dn = de & 31u;
+        put((de >> 5) | (ev << dn), dn + eb); // <= 15 + 13 bits
     }
 };
 
-// Deflate bits of the chunk's tokens without visiting the literals: their four kinds are counted with
-// popcounts, only the matches are walked.
-__device__ __forceinline__ uint32_t gtz_count_bits(const GtzChunk& c, const GtzTokens& t, const uint32_t* farlist, GtzBitCount& cnt)
-{
-    const uint32_t codes[4] = {(uint32_t)c.lo, (uint32_t)(c.lo >> 32), (uint32_t)c.hi, (uint32_t)(c.hi >> 32)};
-    uint32_t n_zero = 0, n_one = 0, n_slash = 0, n_tab = 0, nfar = 0;
-#pragma unroll
-    for (int w = 0; w < 4; ++w) {
-        const uint64_t r = t.run3[w];
-        const uint64_t lit = t.plain[w] & ~r;
-        const uint64_t sp = gtz_spread_pairs(codes[w]);
-        const uint64_t ones = (sp & 0x1111111111111111ull) | ((sp & 0x2222222222222222ull) << 1); // allele bytes that are '1'
-        n_one += (uint32_t)__builtin_popcountll(lit & ones);
-        n_zero += (uint32_t)__builtin_popcountll(lit & 0x5555555555555555ull & ~ones);
-        n_slash += (uint32_t)__builtin_popcountll(lit & 0x2222222222222222ull);
-        n_tab += (uint32_t)__builtin_popcountll(lit & 0x8888888888888888ull);
-        const uint64_t carry = w ? t.run3[w - 1] >> 63 : 0ull;
-        uint64_t T = (r & ~((r << 1) | carry)) | t.far[w];
-        while (T) {
-            const uint32_t p = (uint32_t)__builtin_ctzll(T);
-            T &= T - 1ull;
-            if (t.far[w] & (1ull << p)) {
-                const uint32_t e = farlist[nfar++];
-                cnt.match(4u * ((e >> 6) & 127u), e >> 13);
-            } else {
-                const uint64_t stop = ~r & ~gtz_low_mask(p); // first byte at or after p that is not in the run
-                const uint32_t L = stop ? (uint32_t)__builtin_ctzll(stop) - p : 64u - p + t.ext[w];
-                cnt.match(L, 4u);
-            }
-        }
-    }
-    const uint32_t lb = cnt.lit_bits;
-    cnt.bits += n_zero * (lb & 0xFFu) + n_one * ((lb >> 8) & 0xFFu) + n_slash * ((lb >> 16) & 0xFFu) + n_tab * (lb >> 24);
-    return cnt.bits;
-}
-
-// Visit the chunk's tokens in byte order.
+// Visit the chunk's events in byte order.
 template <class Sink>
-__device__ __forceinline__ void gtz_emit_tokens(const GtzChunk& c, const GtzTokens& t, const uint32_t* farlist, Sink& sink)
+__device__ __forceinline__ void gtz_walk(const GtzChunk& c, const GtzEvents& E, const uint32_t* farlist, Sink& sink)
 {
-    const uint32_t codes[4] = {(uint32_t)c.lo, (uint32_t)(c.lo >> 32), (uint32_t)c.hi, (uint32_t)(c.hi >> 32)};
+    uint32_t at = 4u * c.j0; // chunk byte at which the current gap begins
     uint32_t nfar = 0;
+    GtzMask ev = E.ev;
+    if (c.head && !((c.j0 < 32u ? E.far.lo >> (2u * c.j0) : E.far.hi >> (2u * c.j0 - 64u)) & 1ull)) {
+        // the first cell of a row's region has nothing before it in the member to repeat: four literals
+        const uint32_t code = c.code(c.j0);
+        sink.lit(code & 1u);
+        sink.lit(2u);
+        sink.lit(code >> 1);
+        sink.lit(3u);
+        const GtzMask m = gtz_range(2u * c.j0, 2u * c.j0 + 2u);
+        ev.lo &= ~m.lo;
+        ev.hi &= ~m.hi;
+        at += 4u;
+    }
 #pragma unroll
-    for (int w = 0; w < 4; ++w) {
-        const uint64_t r = t.run3[w];
-        const uint64_t carry = w ? t.run3[w - 1] >> 63 : 0ull;
-        const uint64_t mstart = r & ~((r << 1) | carry);
-        uint64_t T = (t.plain[w] & ~r) | mstart | t.far[w];
+    for (int h = 0; h < 2; ++h) {
+        uint64_t T = h ? ev.hi : ev.lo;
+        const uint64_t F = h ? E.far.hi : E.far.lo, V = h ? c.hi : c.lo;
         while (T) {
-            const uint32_t p = (uint32_t)__builtin_ctzll(T);
+            const uint32_t b = (uint32_t)__builtin_ctzll(T);
             T &= T - 1ull;
-            const uint64_t bit = 1ull << p;
-            if (t.far[w] & bit) {
+            const uint32_t byte = 2u * (64u * (uint32_t)h + b);
+            const uint32_t L = byte - at;
+            if ((F >> b) & 1ull) {
                 const uint32_t e = farlist[nfar++];
-                sink.match(4u * ((e >> 6) & 127u), e >> 13);
-            } else if (r & bit) {
-                // distance-4 match: runs on through the following words while their low bytes stay in the run
-                const uint64_t stop = ~r & ~gtz_low_mask(p); // first byte at or after p that is not in the run
-                const uint32_t L = stop ? (uint32_t)__builtin_ctzll(stop) - p : 64u - p + t.ext[w];
-                sink.match(L, 4u);
+                const uint32_t f = (e >> 6) & 127u;
+                sink.gap_only(L, at);
+                sink.far(f, e >> 13);
+                at = byte + 4u * f;
             } else {
-                const uint32_t which = p & 3u;
-                const uint32_t allele = (codes[w] >> (p >> 1)) & 1u;
-                sink.lit((which & 1u) ? 2u + (which >> 1) : allele);
+                sink.gap_lit(L, at, (uint32_t)(V >> b) & 1u);
+                at = byte + 1u;
             }
         }
     }
-}
-
-// LZ77 matches of one chunk (see gtz_kernels.hip.h).  Lanes step from break to break together; a break is
-// only looked up when the 16 cells from it hold at least GTZ_MIN_BREAKS differing alleles.
-__device__ __forceinline__ void gtz_find_matches(GtzShared* s, uint32_t i, uint32_t c64, const GtzChunk& c, uint32_t* farlist)
-{
-    const uint32_t gbase = 16u * s->gw[i] - 16u * s->kw0[i] + 64u * c64; // g of the chunk's cell 0
-    const uint32_t grow = 16u * s->gw[i];                                // first g of this row
-    const int32_t cs = s->cs[i];
-    const uint64_t blo = (c.xlo | (c.xlo >> 1)) & 0x5555555555555555ull;
-    const uint64_t bhi = (c.xhi | (c.xhi >> 1)) & 0x5555555555555555ull;
-    if (c.j1 < GTZ_KEY_CELLS + c.j0) { farlist[0] = 0; return; }
-    const uint32_t last = c.j1 - GTZ_KEY_CELLS; // last cell a match can start at
-    uint32_t pos = c.j0, nfar = 0;
-    for (;;) {
-        const uint32_t j = gtz_next_break(blo, bhi, pos);
-        if (j > last || nfar >= GTZ_MAX_FAR) break;
-        // alleles that differ from the cell before, in the 16 cells from j
-        const uint32_t xw = j < 32u ? (uint32_t)((c.xlo >> (2u * j)) | (j ? c.xhi << (64u - 2u * j) : 0ull)) : (uint32_t)(c.xhi >> (2u * j - 64u));
-        if ((uint32_t)__builtin_popcount(xw) < GTZ_MIN_BREAKS) { pos = j + 1u; continue; }
-        const uint32_t g = gbase + j;
-        const uint32_t dw = c.window(j);
-        const uint32_t key = dw & (GTZ_KEYS - 1u);
-        const uint32_t q = min(g >> GTZ_SEG_SHIFT, GTZ_SEGS - 1u);
-        // candidates: earliest in this quarter, latest / earliest in the one before, latest two back
-        uint32_t cand[GTZ_CANDS];
-        cand[0] = s->tab16[(2u * q) * GTZ_KEYS + key]; // 0xFFFF (none) is never below g
-        cand[1] = q ? (uint32_t)s->tab16[(2u * (q - 1u) + 1u) * GTZ_KEYS + key] - 1u : 0xFFFFFFFFu;
-        if (GTZ_CANDS > 2) cand[2] = q ? (uint32_t)s->tab16[(2u * (q - 1u)) * GTZ_KEYS + key] : 0xFFFFFFFFu;
-        if (GTZ_CANDS > 3) cand[3] = q > 1u ? (uint32_t)s->tab16[(2u * (q - 2u) + 1u) * GTZ_KEYS + key] - 1u : 0xFFFFFFFFu;
-        const uint32_t room = c.j1 - j;
-        bool ok[GTZ_CANDS], other_row = false;
-        uint32_t sg[GTZ_CANDS], n[GTZ_CANDS], lim[GTZ_CANDS], d[GTZ_CANDS];
-#pragma unroll
-        for (int t = 0; t < (int)GTZ_CANDS; ++t) {
-            ok[t] = cand[t] < g;
-            if (t == 2 && ok[2] && cand[2] == cand[1]) ok[2] = false; // one occurrence in that quarter: same position twice
-            sg[t] = ok[t] ? cand[t] : g; // a disabled candidate reads its own position
-            other_row |= ok[t] && sg[t] < grow;
-        }
-#pragma unroll
-        for (int t = 0; t < (int)GTZ_CANDS; ++t) {
-            const uint32_t xw0 = gtz_window(s->cells, sg[t]) ^ dw;
-            n[t] = xw0 ? (uint32_t)__builtin_ctz(xw0) >> 1 : 16u;
-            lim[t] = room;
-            d[t] = 4u * (g - sg[t]);
-        }
-        if (other_row) { // a source in an earlier row of the member: its own byte distance and end
-#pragma unroll
-            for (int t = 0; t < (int)GTZ_CANDS; ++t) {
-                if (!ok[t] || sg[t] >= grow) continue;
-                uint32_t r = i;
-                while (16u * s->gw[r] > sg[t]) --r;
-                const uint32_t ks = sg[t] - 16u * s->gw[r] + 16u * s->kw0[r];
-                d[t] = (uint32_t)(cs + 4 * (int32_t)(64u * c64 + j) - (s->cs[r] + 4 * (int32_t)ks));
-                lim[t] = min(room, s->ke[r] - ks);
-            }
-        }
-        uint32_t f = 0, dbytes = 0;
-#pragma unroll
-        for (int t = 0; t < (int)GTZ_CANDS; ++t) {
-            // longer than one window: keep comparing (rare except in sparse rows)
-            if (ok[t] && n[t] == 16u)
-                while (n[t] < lim[t]) {
-                    const uint32_t x = c.window(j + n[t]) ^ gtz_window(s->cells, sg[t] + n[t]);
-                    if (x) { n[t] += (uint32_t)__builtin_ctz(x) >> 1; break; }
-                    n[t] += 16u;
-                }
-            const uint32_t nt = (ok[t] && d[t] <= 32768u) ? min(n[t], lim[t]) : 0u;
-            if (nt > f || (nt == f && nt && d[t] < dbytes)) { f = nt; dbytes = d[t]; } // ties: the nearer one
-        }
-        bool take = f >= GTZ_KEY_CELLS;
-        if (take) {
-            const uint32_t a = 2u * j, b = 2u * (j + f);
-            const uint64_t mlo = gtz_low_mask(min(b, 64u)) & ~gtz_low_mask(min(a, 64u));
-            const uint64_t mhi = gtz_low_mask(b > 64u ? b - 64u : 0u) & ~gtz_low_mask(a > 64u ? a - 64u : 0u);
-            take = (uint32_t)(__builtin_popcountll(c.xlo & mlo) + __builtin_popcountll(c.xhi & mhi)) >= GTZ_MIN_BREAKS;
-        }
-        if (take) {
-            farlist[nfar++] = (j - c.j0) | (f << 6) | (dbytes << 13);
-            pos = j + f;
-        } else pos = j + 1u;
-    }
-    if (nfar < GTZ_MAX_FAR) farlist[nfar] = 0; // terminator: a recorded match has cells != 0
+    sink.gap_only(4u * c.j1 - at, at);
 }
 
 } // namespace dnaf
