@@ -105,6 +105,8 @@ struct dnaf_ctx {
     uint16_t* d_thread_bits = nullptr;
     uint32_t* d_crcs = nullptr;
     uint32_t* d_large = nullptr;
+    uint64_t* d_scan_u64 = nullptr; // per-workgroup totals of the member scans
+    uint32_t* d_scan_u32 = nullptr;
     uint64_t* d_offsets = nullptr;
     uint64_t blocks_cap = 0;
     uint8_t* d_bgzf = nullptr;
@@ -246,6 +248,8 @@ int dnaf_destroy(dnaf_ctx* c)
     dev_free(c->d_thread_bits);
     dev_free(c->d_crcs);
     dev_free(c->d_large);
+    dev_free(c->d_scan_u64);
+    dev_free(c->d_scan_u32);
     dev_free(c->d_offsets);
     dev_free(c->d_bgzf);
     dev_free(c->d_bed);
@@ -1061,6 +1065,8 @@ int dnaf_bgzf_compress(dnaf_ctx* c, uint32_t flags, uint64_t* n_bytes)
         dev_free(c->d_thread_bits);
         dev_free(c->d_crcs);
         dev_free(c->d_large);
+        dev_free(c->d_scan_u64);
+        dev_free(c->d_scan_u32);
         dev_free(c->d_offsets);
         dev_free(c->d_member_row);
         dev_free(c->d_fast);
@@ -1074,13 +1080,17 @@ int dnaf_bgzf_compress(dnaf_ctx* c, uint32_t flags, uint64_t* n_bytes)
         if (e == hipSuccess) e = hipMalloc((void**)&c->d_sizes, (uint64_t)nb * sizeof(uint32_t));
         if (e == hipSuccess) e = hipMalloc((void**)&c->d_thread_bits, (uint64_t)nb * dnaf::BGZF_THREADS * sizeof(uint16_t));
         if (e == hipSuccess) e = hipMalloc((void**)&c->d_offsets, ((uint64_t)nb + 1) * sizeof(uint64_t));
+        if (e == hipSuccess) e = hipMalloc((void**)&c->d_scan_u64, ((uint64_t)nb / dnaf::SCAN_BLOCK + 1) * sizeof(uint64_t));
+        if (e == hipSuccess) e = hipMalloc((void**)&c->d_scan_u32, ((uint64_t)nb / dnaf::SCAN_BLOCK + 1) * sizeof(uint32_t));
         if (e != hipSuccess) { // all or nothing: a partial set is not kept
+            dev_free(c->d_scan_u64); dev_free(c->d_scan_u32);
             dev_free(c->d_todo); dev_free(c->d_member_row); dev_free(c->d_fast); dev_free(c->d_crcs);
             dev_free(c->d_large); dev_free(c->d_sizes); dev_free(c->d_thread_bits); dev_free(c->d_offsets);
             return fail(c, e == hipErrorOutOfMemory ? DNAF_ERR_OOM : DNAF_ERR_HIP, "dnaf_bgzf_compress: %s", hipGetErrorString(e));
         }
         c->blocks_cap = nb;
     }
+    const uint32_t scan_blocks = (nb + dnaf::SCAN_BLOCK - 1) / dnaf::SCAN_BLOCK;
     dnaf::BgzfParams p;
     p.text = c->d_text;
     p.n_bytes = tbytes;
@@ -1133,10 +1143,14 @@ int dnaf_bgzf_compress(dnaf_ctx* c, uint32_t flags, uint64_t* n_bytes)
         HIP_TRY(c, hipEventRecord(c->zev[0], c->stream));
         hipLaunchKernelGGL(dnaf::gtz_locate, dim3((nb + 255) / 256), dim3(256), 0, c->stream, g);
         HIP_TRY(c, hipGetLastError());
+        // one item (64-cell chunk or literal span) per thread: a member of long rows has at most 241 + 3 x (rows it
+        // overlaps) of them; where rows are short enough for more than 256, the 512-thread form runs
+        const bool many = 241u + 3u * (dnaf::BGZF_IN / (4u * (g.S ? g.S : 1u)) + 2u) > dnaf::GTZ_THREADS;
         if (!(c->have_gtz_tables && (flags & DNAF_BGZF_REUSE_TABLES))) {
             static thread_local uint32_t h[dnaf::GTZ_NCLASS * dnaf::GTZ_NSYM];
             HIP_TRY(c, hipMemsetAsync(c->d_gtz_hist, 0, sizeof h, c->stream));
-            hipLaunchKernelGGL((dnaf::gtz_encode<true>), dim3((nb + g.sample_step - 1) / g.sample_step), dim3(dnaf::GTZ_THREADS), 0, c->stream, g);
+            if (many) hipLaunchKernelGGL((dnaf::gtz_encode<true, dnaf::GTZ_THREADS_MANY>), dim3((nb + g.sample_step - 1) / g.sample_step), dim3(dnaf::GTZ_THREADS_MANY), 0, c->stream, g);
+            else hipLaunchKernelGGL((dnaf::gtz_encode<true, dnaf::GTZ_THREADS>), dim3((nb + g.sample_step - 1) / g.sample_step), dim3(dnaf::GTZ_THREADS), 0, c->stream, g);
             HIP_TRY(c, hipGetLastError());
             HIP_TRY(c, hipMemcpyAsync(h, c->d_gtz_hist, sizeof h, hipMemcpyDeviceToHost, c->stream));
             HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -1145,9 +1159,11 @@ int dnaf_bgzf_compress(dnaf_ctx* c, uint32_t flags, uint64_t* n_bytes)
             HIP_TRY(c, hipMemcpy(c->d_gtz_tables, &gt, sizeof gt, hipMemcpyHostToDevice));
             c->have_gtz_tables = true;
         }
-        hipLaunchKernelGGL((dnaf::gtz_encode<false>), dim3(nb), dim3(dnaf::GTZ_THREADS), 0, c->stream, g);
+        if (many) hipLaunchKernelGGL((dnaf::gtz_encode<false, dnaf::GTZ_THREADS_MANY>), dim3(nb), dim3(dnaf::GTZ_THREADS_MANY), 0, c->stream, g);
+        else hipLaunchKernelGGL((dnaf::gtz_encode<false, dnaf::GTZ_THREADS>), dim3(nb), dim3(dnaf::GTZ_THREADS), 0, c->stream, g);
         HIP_TRY(c, hipGetLastError());
-        hipLaunchKernelGGL(dnaf::bgzf_list_unset, dim3(1), dim3(1024), 0, c->stream, (const uint8_t*)c->d_fast, nb, c->d_todo);
+        hipLaunchKernelGGL(dnaf::bgzf_unset_totals, dim3(scan_blocks), dim3(dnaf::SCAN_THREADS), 0, c->stream, (const uint8_t*)c->d_fast, nb, c->d_scan_u32);
+        hipLaunchKernelGGL(dnaf::bgzf_unset_apply, dim3(scan_blocks), dim3(dnaf::SCAN_THREADS), 0, c->stream, (const uint8_t*)c->d_fast, nb, (const uint32_t*)c->d_scan_u32, c->d_todo);
         HIP_TRY(c, hipGetLastError());
         HIP_TRY(c, hipEventRecord(c->zev[1], c->stream));
         HIP_TRY(c, hipMemcpyAsync(&n_todo, c->d_todo, sizeof n_todo, hipMemcpyDeviceToHost, c->stream));
@@ -1183,7 +1199,9 @@ int dnaf_bgzf_compress(dnaf_ctx* c, uint32_t flags, uint64_t* n_bytes)
         HIP_TRY(c, hipGetLastError());
     }
     uint32_t n_large = 0;
-    hipLaunchKernelGGL(dnaf::bgzf_scan, dim3(1), dim3(1024), 0, c->stream, (const uint32_t*)c->d_sizes, nb, c->d_offsets, c->d_large);
+    hipLaunchKernelGGL(dnaf::bgzf_scan_totals, dim3(scan_blocks), dim3(dnaf::SCAN_THREADS), 0, c->stream, (const uint32_t*)c->d_sizes, nb, c->d_scan_u64, c->d_scan_u32);
+    hipLaunchKernelGGL(dnaf::bgzf_scan_apply, dim3(scan_blocks), dim3(dnaf::SCAN_THREADS), 0, c->stream, (const uint32_t*)c->d_sizes, nb, (const uint64_t*)c->d_scan_u64,
+                       (const uint32_t*)c->d_scan_u32, c->d_offsets, c->d_large);
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipEventRecord(c->zev[1], c->stream));
     HIP_TRY(c, hipMemcpyAsync(&total, c->d_offsets + nb, sizeof total, hipMemcpyDeviceToHost, c->stream));

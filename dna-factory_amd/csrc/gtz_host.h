@@ -30,18 +30,18 @@ constexpr uint32_t GTZ_GAP_STRIDE = 264; // entries per half of the gap table (g
 struct GtzClassTables {
     uint32_t lit[256];   // literal byte -> code
     uint32_t len[256];   // match length L (index L - 3) -> length code + extra bits (<= 20 bits)
-    // gap[h][L]: the L bytes between two events of a chunk (gtz_tokens.hip.h), every one repeating the byte four back:
-    // L >= 3 one match (length code + extra bits + the code of distance 4), L = 1 the separator's literal -- '/' in
-    // half 0 (the gap begins behind allele a), '\t' in half 1 (behind allele b) --, L = 0 nothing.  At most 27 bits.
-    uint32_t gap[2 * GTZ_GAP_STRIDE];
-    uint32_t len4[GTZ_CHUNK_CELLS + 8]; // LZ77 match of f cells (4 f bytes) -> length code + extra bits
-    uint32_t unit_ok;    // 1: a gap code and the literal '0' / '1' behind it fit 32 bits together (what the kernel emits as one unit)
     uint32_t dist[32];   // distance symbol -> code (extra bits are appended by the kernel)
     uint32_t eob;
     uint32_t hdr_nbits;
     uint32_t hdr[GTZ_HDR_WORDS];
     uint64_t len_nb[2];  // code length of length symbol 257 + n at nibble n (the bit-count pass works from registers)
     uint64_t dist_nb[2]; // code length of distance symbol n at nibble n
+    // gap[h][L]: the L bytes between two events of a chunk (gtz_tokens.hip.h), every one repeating the byte four back:
+    // L >= 3 one match (length code + extra bits + the code of distance 4), L = 1 the separator's literal -- '/' in
+    // half 0 (the gap begins behind allele a), '\t' in half 1 (behind allele b) --, L = 0 nothing.  At most 27 bits.
+    uint32_t gap[2 * GTZ_GAP_STRIDE];
+    uint32_t len4[GTZ_CHUNK_CELLS + 8]; // LZ77 match of f cells (4 f bytes) -> length code + extra bits
+    uint32_t unit_ok;    // 1: a gap code and the literal '0' / '1' behind it fit 32 bits together (what the kernel emits as one unit)
 };
 
 struct GtzTables {

@@ -33,23 +33,34 @@
 
 namespace dnaf {
 
-constexpr uint32_t GTZ_THREADS = 256;
-constexpr uint32_t GTZ_WAVES = GTZ_THREADS / 64;
+constexpr uint32_t GTZ_THREADS = 256;      // one item (64-cell chunk or literal span) per thread: members of long rows (up to 256 items)
+constexpr uint32_t GTZ_THREADS_MANY = 512; // members of short rows: more rows, hence more spans and cut chunks
+constexpr uint32_t GTZ_MAX_WAVES = GTZ_THREADS_MANY / 64;
 constexpr uint32_t GTZ_KEY_CELLS = 5;
 constexpr uint32_t GTZ_KEYS = 1u << (2 * GTZ_KEY_CELLS);
-constexpr uint32_t GTZ_SEGS = 4;          // quarters of the member's g space (4096 cells each)
-constexpr uint32_t GTZ_SEG_SHIFT = 12;
+#ifndef DNAF_GTZ_SEGS
+#define DNAF_GTZ_SEGS 3
+#endif
+constexpr uint32_t GTZ_SEGS = DNAF_GTZ_SEGS;                 // segments of the member's g space, each with its own key tables
+constexpr uint32_t GTZ_SEG_CELLS = GTZ_SEGS == 4 ? 4096 : 5120; // 4 x 4096 (the last one open-ended) or 3 x 5120
+static_assert(GTZ_SEGS == 3 || GTZ_SEGS == 4, "segments");
+__device__ __forceinline__ uint32_t gtz_segment(uint32_t g)
+{
+    return GTZ_SEGS == 4 ? min(g >> 12, 3u) : (g >= GTZ_SEG_CELLS ? 1u : 0u) + (g >= 2u * GTZ_SEG_CELLS ? 1u : 0u);
+}
 constexpr uint32_t GTZ_MAX_ROWS = 16;     // rows overlapping one member
 constexpr uint32_t GTZ_MAX_CHUNKS = 240 + 2 * GTZ_MAX_ROWS;
-constexpr uint32_t GTZ_MAX_ITEMS = 2 * GTZ_THREADS; // chunks + literal spans, two per thread
 constexpr uint32_t GTZ_MAX_FAR = 12;      // LZ77 matches recorded per chunk (64 cells / 5)
 constexpr uint32_t GTZ_CELL_WORDS = BGZF_IN / 64 + 2 * GTZ_MAX_ROWS + 8;
-constexpr uint32_t GTZ_STRIDE = 16384;    // staging slot of a member
-constexpr uint32_t GTZ_OUT_WORDS = GTZ_STRIDE / 4;
+constexpr uint32_t GTZ_STRIDE = 16384;    // staging slot of a member (global memory)
+constexpr uint32_t GTZ_IMAGE_WORDS = 3840; // the member image in LDS: 15,360 bytes, as much as the search's tables it overlays (a
+                                           // member of MAF-0.5 rows takes 8 KB; a larger one goes to the text-domain encoder)
 constexpr uint32_t GTZ_MIN_BREAKS = 3;    // an LZ77 match must replace at least this many literal bytes
-constexpr uint32_t GTZ_CANDS = 4;         // source candidates looked at per break (2..4)
-static_assert(2 * GTZ_SEGS * GTZ_KEYS * 2 == GTZ_OUT_WORDS * 4, "the member image reuses the key tables");
-static_assert(GTZ_MAX_CHUNKS * GTZ_MAX_FAR >= 2 * GTZ_KEYS, "the match lists lend their space to the table build");
+#ifndef DNAF_GTZ_CANDS
+#define DNAF_GTZ_CANDS 2
+#endif
+constexpr uint32_t GTZ_CANDS = DNAF_GTZ_CANDS; // source candidates looked at per break (2..4)
+constexpr uint32_t GTZ_SPAN_MAX = 72;     // bytes between two rows' cell regions: last cell + "\n" + fixed columns + a cut cell
 
 struct GtzParams {
     const RowRec* recs;      // [table rows]
@@ -86,14 +97,28 @@ __global__ __launch_bounds__(256) void gtz_locate(const GtzParams p)
     p.member_row[m] = (uint32_t)(lo - p.row_begin);
 }
 
+// a row of the member as the search sees it: g-space bounds of its cells inside the member, and the offset that turns
+// a g-space position into a byte of the member (byte = 4 g + delta)
+struct GtzRowInfo {
+    int32_t delta;
+    uint32_t gfirst, gend;
+    uint32_t pad;
+};
+
 struct GtzShared {
     union {
-        uint16_t tab16[2 * GTZ_SEGS * GTZ_KEYS]; // [quarter][0 = earliest (0xFFFF: none), 1 = latest + 1 (0: none)][key]
-        uint32_t image[GTZ_OUT_WORDS];           // later the member image
+        struct { // the search's view: key tables and the cells
+            uint16_t tab16[(2 * GTZ_SEGS - 1) * GTZ_KEYS]; // [quarter][0 = earliest (0xFFFF: none), 1 = latest + 1 (0: none)][key]; the last quarter has no "latest"
+            uint32_t cells[GTZ_CELL_WORDS + 4];
+            uint8_t rowmap[GTZ_CELL_WORDS + 8]; // row (index into the arrays below) of every g-space word
+        };
+        uint32_t image[GTZ_IMAGE_WORDS];         // later the member image
     };
-    uint32_t cells[GTZ_CELL_WORDS + 4];
-    uint32_t far[GTZ_MAX_CHUNKS * GTZ_MAX_FAR]; // cell in chunk | cells << 6 | distance in bytes << 13
-    uint32_t codes[256 + 2 * GTZ_GAP_STRIDE + GTZ_CHUNK_CELLS + 8 + 32]; // lit, gap, len4, dist code tables; the symbol histogram in gtz_encode<true>
+    GtzRowInfo row[GTZ_MAX_ROWS + 2];
+#ifdef DNAF_GTZ_PAD_LDS
+    uint32_t pad_lds[DNAF_GTZ_PAD_LDS]; // occupancy experiments
+#endif
+    uint32_t codes[128 + 2 * GTZ_GAP_STRIDE + GTZ_CHUNK_CELLS + 8 + 32]; // lit, gap, len4, dist code tables; the symbol histogram in gtz_encode<true>
     uint32_t crc_table[256];
     uint32_t crc_base[GTZ_CHUNK_CELLS + 1];
     uint32_t crc_unit_a[2 * GTZ_CHUNK_CELLS]; // first allele's units, then (crc_unit_b) the second allele's
@@ -109,15 +134,16 @@ struct GtzShared {
     int32_t span_lo[GTZ_MAX_ROWS + 2], span_hi[GTZ_MAX_ROWS + 2];
     uint32_t thr0[GTZ_MAX_ROWS + 2];
     uint8_t cls[GTZ_MAX_ROWS + 2], nall[GTZ_MAX_ROWS + 2];
-    uint32_t scratch[3 * GTZ_WAVES];
+    uint8_t span_bytes[(GTZ_MAX_ROWS + 2) * GTZ_SPAN_MAX]; // the literal spans' text
+    uint32_t scratch[2 * GTZ_MAX_WAVES];
     uint32_t nr, n_items, ok, klass;
     __device__ __forceinline__ uint32_t* lit() { return codes; }
-    __device__ __forceinline__ uint32_t* gap() { return codes + 256; }
-    __device__ __forceinline__ uint32_t* len4() { return codes + 256 + 2 * GTZ_GAP_STRIDE; }
-    __device__ __forceinline__ uint32_t* dist() { return codes + 256 + 2 * GTZ_GAP_STRIDE + GTZ_CHUNK_CELLS + 8; }
+    __device__ __forceinline__ uint32_t* gap() { return codes + 128; }
+    __device__ __forceinline__ uint32_t* len4() { return codes + 128 + 2 * GTZ_GAP_STRIDE; }
+    __device__ __forceinline__ uint32_t* dist() { return codes + 128 + 2 * GTZ_GAP_STRIDE + GTZ_CHUNK_CELLS + 8; }
     __device__ __forceinline__ uint32_t* hist() { return codes; }
 };
-static_assert(GTZ_NSYM <= 256 + 2 * GTZ_GAP_STRIDE, "the histogram reuses the code tables");
+static_assert(GTZ_NSYM <= 128 + 2 * GTZ_GAP_STRIDE, "the histogram reuses the code tables");
 
 // 16 cells of the 2-bit stream starting at g
 __device__ __forceinline__ uint32_t gtz_window(const uint32_t* cells, uint32_t g)
@@ -264,12 +290,24 @@ __device__ unsigned long long gtz_prof[16];
 #define GTZ_STAMP(k) do { } while (0)
 #endif
 
+#ifndef DNAF_GTZ_BREAK_KEYS
+#define DNAF_GTZ_BREAK_KEYS 0 // key tables hold only positions whose cell differs from the cell before
+#endif
+#ifndef DNAF_GTZ_TAB2
+#define DNAF_GTZ_TAB2 0 // key tables by two sweeps of plain stores instead of one with a read
+#endif
 #ifndef DNAF_GTZ_EXP
 #define DNAF_GTZ_EXP 0 // timing experiments (output invalid): 1 no search, 2 no emission walk, 3 no count walk, 4 no key tables, 5 no CRC
 #endif
-template <bool HIST>
-__global__ __launch_bounds__(GTZ_THREADS) void gtz_encode(const GtzParams p)
+#ifdef DNAF_GTZ_WAVES_PER_EU
+#define GTZ_OCCUPANCY __attribute__((amdgpu_waves_per_eu(DNAF_GTZ_WAVES_PER_EU, 8)))
+#else
+#define GTZ_OCCUPANCY
+#endif
+template <bool HIST, uint32_t THREADS>
+__global__ __launch_bounds__(THREADS) GTZ_OCCUPANCY void gtz_encode(const GtzParams p)
 {
+    constexpr uint32_t WAVES = THREADS / 64u;
 #ifdef DNAF_GTZ_PROFILE
     unsigned long long t_prev_ = __builtin_amdgcn_s_memtime();
 #endif
@@ -302,7 +340,7 @@ __global__ __launch_bounds__(GTZ_THREADS) void gtz_encode(const GtzParams p)
     }
     __syncthreads();
     if (tid == 0) {
-        uint32_t nr = 0, ok = HIST ? 1u : p.tables->cls[0].unit_ok; // (every class is built alike: one flag says it for all)
+        uint32_t nr = 0, ok = 1;
         while (nr <= GTZ_MAX_ROWS && s->off[nr] != 0x7FFFFFFF) ++nr;
         if (nr > GTZ_MAX_ROWS || p.S < 2u) ok = 0;
         uint32_t items = 0, chunks = 0, words = 0, best_cells = 0, best_row = 0;
@@ -337,13 +375,16 @@ __global__ __launch_bounds__(GTZ_THREADS) void gtz_encode(const GtzParams p)
         s->span_lo[nr] = prev_end;
         s->span_hi[nr] = (int32_t)N;
         items += 1u;
-        if (items > GTZ_MAX_ITEMS || chunks > GTZ_MAX_CHUNKS || words + 1u > GTZ_CELL_WORDS) ok = 0;
+        if (items > THREADS || words + 1u > GTZ_CELL_WORDS) ok = 0; // (the host launches the 512-thread form where rows are short)
+        for (uint32_t i = 0; i <= nr && ok; ++i)
+            if (s->span_hi[i] - s->span_lo[i] > (int32_t)GTZ_SPAN_MAX) ok = 0;
         s->nr = nr;
         s->n_items = items;
         s->ok = ok;
         // table class from the alternative-allele frequency of the row that fills most of the member
         const float q = 1.0f - ((float)s->thr0[best_row] + 1.0f) * (1.0f / 4294967296.0f);
         s->klass = q < 0.02f ? 0u : q < 0.04f ? 1u : q < 0.08f ? 2u : q < 0.13f ? 3u : q < 0.2f ? 4u : q < 0.3f ? 5u : q < 0.4f ? 6u : 7u;
+        if (!HIST && !p.tables->cls[s->klass].unit_ok) s->ok = 0; // this class's codes do not fit the walk's 32-bit units
     }
     __syncthreads();
     if (!s->ok) {
@@ -358,117 +399,129 @@ __global__ __launch_bounds__(GTZ_THREADS) void gtz_encode(const GtzParams p)
     for (uint32_t i = 0; i < nr; ++i) {
         const uint32_t nw = s->gw[i + 1] - s->gw[i];
         const uint32_t* src = p.packed + (uint64_t)(m_row + i) * p.Wp;
-        for (uint32_t w = tid; w < nw; w += GTZ_THREADS) {
+        for (uint32_t w = tid; w < nw; w += THREADS) {
             const uint32_t kw = s->kw0[i] + w;
             s->cells[s->gw[i] + w] = kw < p.W ? src[kw] : 0u;
+            s->rowmap[s->gw[i] + w] = (uint8_t)i;
         }
     }
-    if (tid < 4) s->cells[s->gw[nr] + tid] = 0;
+    if (tid < 4) { s->cells[s->gw[nr] + tid] = 0; s->rowmap[s->gw[nr] + tid] = (uint8_t)nr; }
+    if (tid <= nr) {
+        GtzRowInfo ri{0, 0, 0, 0}; // entry nr: the padding behind the last row, empty bounds
+        if (tid < nr) {
+            const int32_t g0 = 16 * (int32_t)s->gw[tid] - 16 * (int32_t)s->kw0[tid]; // g of the row's cell 0
+            ri.delta = s->cs[tid] - 4 * g0;
+            ri.gfirst = (uint32_t)(g0 + (int32_t)s->kb[tid]);
+            ri.gend = (uint32_t)(g0 + (int32_t)s->ke[tid]);
+        }
+        s->row[tid] = ri;
+    }
+    // the text between the rows' cell regions (one global load per byte, all in flight together)
+    for (uint32_t t = tid; t < (nr + 1u) * GTZ_SPAN_MAX; t += THREADS) {
+        const uint32_t i = t / GTZ_SPAN_MAX;
+        const int32_t pos = s->span_lo[i] + (int32_t)(t - i * GTZ_SPAN_MAX);
+        if (pos < s->span_hi[i]) {
+            const uint32_t b = gtz_text_byte(p, s, m_row, i, pos);
+            s->span_bytes[t] = (uint8_t)b;
+            if (!HIST && b >= 128u) s->ok = 0; // the literal table in LDS holds the ASCII half (VCF text of this build is ASCII)
+        }
+    }
     if (HIST) {
-        for (uint32_t t = tid; t < GTZ_NSYM; t += GTZ_THREADS) s->hist()[t] = 0;
+        for (uint32_t t = tid; t < GTZ_NSYM; t += THREADS) s->hist()[t] = 0;
     } else {
-        s->lit()[tid] = ct->lit[tid];
-        for (uint32_t t = tid; t < 2 * GTZ_GAP_STRIDE; t += GTZ_THREADS) s->gap()[t] = ct->gap[t];
+        if (tid < 128) s->lit()[tid] = ct->lit[tid];
+        for (uint32_t t = tid; t < 2 * GTZ_GAP_STRIDE; t += THREADS) s->gap()[t] = ct->gap[t];
         if (tid < GTZ_CHUNK_CELLS + 8) s->len4()[tid] = ct->len4[tid];
         if (tid < 32) s->dist()[tid] = ct->dist[tid];
-        s->crc_table[tid] = p.tables->crc_table[tid];
+        if (tid < 256) s->crc_table[tid] = p.tables->crc_table[tid];
         if (tid <= GTZ_CHUNK_CELLS) s->crc_base[tid] = p.tables->crc_base[tid];
         if (tid < GTZ_CHUNK_CELLS) { s->crc_unit_a[tid] = p.tables->crc_unit_a[tid]; s->crc_unit_a[GTZ_CHUNK_CELLS + tid] = p.tables->crc_unit_b[tid]; }
     }
     __syncthreads();
+    if (!s->ok) { // a byte the literal table does not hold
+        if (!HIST && tid == 0) p.fast[m] = 0;
+        return;
+    }
     GTZ_STAMP(1); // cells and code tables in LDS
-    // Key tables, one quarter of the g space at a time: earliest / latest position of every key with 32-bit LDS
-    // atomics in a scratch area (the match lists' space, not yet in use), then narrowed to 16 bits -- the tables
-    // that stay are 16 KB instead of 32, which is what lets a fourth workgroup share the CU.
-    // A quarter is 256 g-space words, one per thread: the thread slides the 5-cell key over its word's 16 positions
-    // in registers (rows start on word boundaries of the g space, so a word belongs to one row).  Of a run of equal
-    // keys only its first position can be the earliest and only its last the latest, so the others stay away from
-    // the table: long stretches of "0/0" would otherwise send every atomic to one LDS address.
+    // Key tables: for every quarter of the g space the earliest and the latest position of every 5-cell key, 16-bit
+    // entries.  No atomics and no validity tests: the threads sweep a quarter in ascending order, 256 consecutive
+    // positions per step -- "latest" is a plain store (the last step that holds the key wins), "earliest" a store where
+    // the entry is still empty.  Waves drift apart by a step or two and lanes of one step race, so both are
+    // approximate (some occurrence near the end / the beginning); the search verifies whatever it finds against the
+    // cells themselves and against the bounds of the source's row, so any position that is entered is harmless.
+    // Only positions whose cell differs from the cell before are entered (DNAF_GTZ_BREAK_KEYS): the search looks keys
+    // up at such positions only, and the long stretches of "0/0" stay away from the tables.
     {
-        uint32_t* scr = s->far; // [0, KEYS): earliest, [KEYS, 2 KEYS): latest + 1
-        const uint32_t total_words = s->gw[nr];
-        for (uint32_t q = 0; q < (DNAF_GTZ_EXP == 4 ? 0u : GTZ_SEGS); ++q) {
-            for (uint32_t t = tid; t < 2 * GTZ_KEYS; t += GTZ_THREADS) scr[t] = t < GTZ_KEYS ? 0xFFFFFFFFu : 0u;
-            __syncthreads();
-            const uint32_t wq = (q << (GTZ_SEG_SHIFT - 4u)) + tid; // this thread's word; the last quarter takes what is left
-            for (uint32_t w = wq; w < total_words; w += GTZ_THREADS) {
-                if (q + 1u < GTZ_SEGS && w != wq) break; // only the last quarter is open-ended
-                uint32_t i = 0;
-                while (i + 1u < nr && s->gw[i + 1] <= w) ++i;
-                const uint32_t kb = s->kb[i], ke = s->ke[i];
-                const uint32_t gbase = 16u * s->gw[i] - 16u * s->kw0[i];
-                // positions of the row at which a whole key lies inside the member: [g_first, g_end)
-                const uint32_t g_first = gbase + kb, g_end = ke - kb < GTZ_KEY_CELLS ? g_first : gbase + ke - GTZ_KEY_CELLS + 1u;
-                const uint32_t g0 = 16u * w;
-                const uint32_t lo = max(g0, g_first), hi = min(g0 + 16u, g_end);
-                const bool any = lo < hi;
-                const uint64_t v = ((uint64_t)s->cells[w + 1] << 32) | s->cells[w];
-                // neighbours across the lanes: the last key of the word before, the first key of the word after
-                const uint32_t key_first = (uint32_t)v & (GTZ_KEYS - 1u), key_last = (uint32_t)(v >> 30) & (GTZ_KEYS - 1u);
-                const bool full = any && lo == g0 && hi == g0 + 16u;
-                const uint32_t lane = tid & 63u;
-                const uint32_t prev_last = __shfl_up(full ? key_last : 0xFFFFFFFFu, 1, 64);
-                const uint32_t next_first = __shfl_down(full ? key_first : 0xFFFFFFFFu, 1, 64);
-                if (any) {
-                    // the key at the position before (0xFFFFFFFF: none that is entered, so this one counts)
-                    uint32_t before = lane && lo == g0 ? prev_last : 0xFFFFFFFFu;
-#pragma unroll
-                    for (uint32_t j = 0; j < 16u; ++j) {
-                        const uint32_t g = g0 + j;
-                        const uint32_t key = (uint32_t)(v >> (2u * j)) & (GTZ_KEYS - 1u);
-                        const bool live = g >= lo && g < hi;
-                        // the key at the position after, if that position is entered too
-                        const uint32_t after = j < 15u ? (g + 1u < hi ? (uint32_t)(v >> (2u * j + 2u)) & (GTZ_KEYS - 1u) : 0xFFFFFFFFu)
-                                                       : (lane < 63u ? next_first : 0xFFFFFFFFu);
-                        if (live && before != key) atomicMin(&scr[key], g);
-                        if (live && after != key) atomicMax(&scr[GTZ_KEYS + key], g + 1u);
-                        before = live ? key : 0xFFFFFFFFu;
-                    }
-                }
-            }
-            __syncthreads();
-            for (uint32_t t = tid; t < 2 * GTZ_KEYS; t += GTZ_THREADS) s->tab16[2u * q * GTZ_KEYS + t] = (uint16_t)min(scr[t], 0xFFFFu);
-            __syncthreads();
+        for (uint32_t t = tid; t < (2 * GTZ_SEGS - 1) * GTZ_KEYS / 2; t += THREADS) { // [quarter][earliest, latest + 1][key], two entries per word
+            const uint32_t which = (t / (GTZ_KEYS / 2u)) & 1u;
+            reinterpret_cast<uint32_t*>(s->tab16)[t] = which ? 0u : 0xFFFFFFFFu;
         }
+        __syncthreads();
+        const uint32_t total = DNAF_GTZ_EXP == 4 ? 0u : 16u * s->gw[nr];
+#if DNAF_GTZ_TAB2
+        // two sweeps of plain stores, no read in between: ascending for "latest", descending for "earliest"
+        const uint32_t steps = (total + THREADS - 1u) / THREADS;
+        for (uint32_t st = 0; st < steps; ++st) {
+            const uint32_t g = st * THREADS + tid;
+            const uint32_t gd = (steps - 1u - st) * THREADS + tid;
+            if (g < total) {
+                const uint32_t q = gtz_segment(g);
+                if (q + 1u < GTZ_SEGS) s->tab16[(2u * q + 1u) * GTZ_KEYS + (gtz_window(s->cells, g) & (GTZ_KEYS - 1u))] = (uint16_t)(g + 1u);
+            }
+            if (gd < total) {
+                const uint32_t q = gtz_segment(gd);
+                s->tab16[(2u * q) * GTZ_KEYS + (gtz_window(s->cells, gd) & (GTZ_KEYS - 1u))] = (uint16_t)gd;
+            }
+        }
+#else
+        for (uint32_t g = tid; g < total; g += THREADS) {
+            const uint32_t q = gtz_segment(g);
+            uint32_t key;
+            bool enter = true;
+            if (DNAF_GTZ_BREAK_KEYS && g) {
+                const uint32_t w = gtz_window(s->cells, g - 1u);
+                key = (w >> 2) & (GTZ_KEYS - 1u);
+                enter = ((w ^ (w >> 2)) & 3u) != 0u;
+            } else key = gtz_window(s->cells, g) & (GTZ_KEYS - 1u);
+            if (enter) {
+                uint16_t* e = &s->tab16[(2u * q) * GTZ_KEYS + key];
+                if (*e == 0xFFFFu) *e = (uint16_t)g;
+                if (q + 1u < GTZ_SEGS) e[GTZ_KEYS] = (uint16_t)(g + 1u);
+            }
+        }
+#endif
+        __syncthreads();
     }
 
     GTZ_STAMP(2); // key tables
     // code lengths of the four literals a cell is made of, one byte each
     const uint32_t lit_bits = HIST ? 0u : (s->lit()['0'] & 31u) | ((s->lit()['1'] & 31u) << 8) | ((s->lit()['/'] & 31u) << 16) | ((s->lit()['\t'] & 31u) << 24);
-    // ---- pass 1: search, then tokenise to count bits (or symbols); CRC ----
-    uint32_t bits[2] = {0, 0}, part = 0;
-    uint32_t it_row[2];
-    bool it_span[2];
-    GtzChunk ch[2];
-    const uint32_t* it_far[2];
-    GtzEvents evs[2];
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-        const uint32_t it = tid + (uint32_t)u * GTZ_THREADS;
-        it_row[u] = 0xFFFFFFFFu;
-        it_span[u] = false;
-        it_far[u] = s->far;
-        ch[u] = GtzChunk{0, 0, 0, 0, 0, 0, false};
-        if (it >= n_items) continue;
+    // ---- pass 1: this thread's item -- a literal span or a 64-cell chunk: search, then count bits (or symbols); CRC ----
+    uint32_t bits = 0, part = 0;
+    uint32_t it_row = 0xFFFFFFFFu;
+    bool it_span = false;
+    GtzChunk ch{0, 0, 0, 0, 0, 0, false};
+    GtzEvents evs;
+    if (tid < n_items) {
         uint32_t i = 0;
-        while (i < nr && s->item_base[i + 1] <= it) ++i; // row (or nr: the closing span)
-        it_row[u] = i;
-        const uint32_t local = it - s->item_base[i];
+        while (i < nr && s->item_base[i + 1] <= tid) ++i; // row (or nr: the closing span)
+        it_row = i;
+        const uint32_t local = tid - s->item_base[i];
         uint32_t crc = 0, nbytes = 0;
         int32_t end_byte = 0;
         if (local == 0u) {
             // literal span: bytes between two rows' cell regions
             const int32_t lo = s->span_lo[i], hi = s->span_hi[i];
-            it_span[u] = true;
+            it_span = true;
             uint32_t c = 0xFFFFFFFFu;
             GtzCount cnt{s, 0};
             GtzHist hs{s};
             for (int32_t pos = lo; pos < hi; ++pos) {
-                const uint32_t b = gtz_text_byte(p, s, m_row, i, pos);
+                const uint32_t b = s->span_bytes[i * GTZ_SPAN_MAX + (uint32_t)(pos - lo)];
                 if (HIST) hs.lit(b);
                 else { cnt.lit(b); c = s->crc_table[(c ^ b) & 0xFFu] ^ (c >> 8); }
             }
-            bits[u] = cnt.bits;
+            bits = cnt.bits;
             crc = ~c;
             nbytes = (uint32_t)(hi - lo);
             end_byte = hi;
@@ -476,27 +529,24 @@ __global__ __launch_bounds__(GTZ_THREADS) void gtz_encode(const GtzParams p)
             const uint32_t kb = s->kb[i], ke = s->ke[i];
             const uint32_t c64 = (kb >> 6) + local - 1u;
             const uint32_t k0 = max(kb, 64u * c64), k1 = min(ke, 64u * c64 + 64u);
-            uint32_t* farlist = s->far + (s->chunk_base[i] + local - 1u) * GTZ_MAX_FAR;
-            it_far[u] = farlist;
-            ch[u] = gtz_load_chunk(s, i, c64, k0, k1);
-            evs[u] = gtz_find_matches(s, i, c64, ch[u], farlist, DNAF_GTZ_EXP != 1);
+            ch = gtz_load_chunk(s, i, c64, k0, k1);
+            evs = gtz_find_matches(s, i, c64, ch, DNAF_GTZ_EXP != 1);
             if (HIST) {
                 GtzSymbolCount hs{s->hist()};
-                gtz_walk(ch[u], evs[u], farlist, hs);
+                gtz_walk(ch, evs, hs);
             } else {
                 GtzBitCount cnt{s->gap(), s->len4(), s->dist(), lit_bits, 0};
-                if (DNAF_GTZ_EXP != 3) gtz_walk(ch[u], evs[u], farlist, cnt);
-                bits[u] = DNAF_GTZ_EXP == 3 ? 150u : cnt.bits;
+                if (DNAF_GTZ_EXP != 3) gtz_walk(ch, evs, cnt);
+                bits = DNAF_GTZ_EXP == 3 ? 150u : cnt.bits;
                 // CRC of the chunk's bytes from its cells: base pattern + one unit per '1' allele.  Only the set bits of the
                 // chunk's code words are visited (a tenth to a third of the 128 alleles), not every cell.
                 const uint32_t n = k1 - k0;
                 uint32_t cc = s->crc_base[n];
                 {
-                    const uint32_t a = 2u * ch[u].j0, b = 2u * ch[u].j1;
-                    uint64_t wlo = ch[u].lo & gtz_low_mask(min(b, 64u)) & ~gtz_low_mask(min(a, 64u));
-                    uint64_t whi = ch[u].hi & gtz_low_mask(b > 64u ? b - 64u : 0u) & ~gtz_low_mask(a > 64u ? a - 64u : 0u);
+                    const GtzMask in = gtz_range(2u * ch.j0, 2u * ch.j1);
+                    uint64_t wlo = ch.lo & in.lo, whi = ch.hi & in.hi;
                     const uint32_t* unit = s->crc_unit_a; // crc_unit_b follows it: [allele][cells before the end]
-                    const uint32_t last = ch[u].j1 - 1u;
+                    const uint32_t last = ch.j1 - 1u;
                     while (DNAF_GTZ_EXP != 5 && (wlo | whi)) {
                         const bool low = wlo != 0;
                         const uint64_t w = low ? wlo : whi;
@@ -516,46 +566,44 @@ __global__ __launch_bounds__(GTZ_THREADS) void gtz_encode(const GtzParams p)
             const uint32_t q = after >> 6, r = after & 63u;
             uint32_t shift = p.tables->crc_shift_chunk[q];
             if (r) shift = crc_mulmod(shift, p.tables->crc_shift_byte[r]);
-            part ^= after ? crc_mulmod(shift, crc) : crc;
+            part = after ? crc_mulmod(shift, crc) : crc;
         }
     }
     if (HIST) {
         __syncthreads();
-        for (uint32_t t = tid; t < GTZ_NSYM; t += GTZ_THREADS)
+        for (uint32_t t = tid; t < GTZ_NSYM; t += THREADS)
             if (s->hist()[t]) atomicAdd(&p.hist[klass * GTZ_NSYM + t], s->hist()[t]);
         if (tid == 0) atomicAdd(&p.hist[klass * GTZ_NSYM + 256u], 1u); // end of block
         return;
     }
 
-    // ---- offsets: exclusive scan of the items' bit counts (items tid, then items 256 + tid) ----
-    GTZ_STAMP(3); // thread 0's own search + tokens + count + CRC (not the slowest thread's)
+    // ---- offsets: exclusive scan of the items' bit counts ----
+    GTZ_STAMP(3); // thread 0's own search + count + CRC (not the slowest thread's)
     const uint32_t lane = tid & 63u, wave = tid >> 6;
-    uint32_t incl0 = bits[0], incl1 = bits[1];
+    uint32_t incl = bits;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t n0 = __shfl_up(incl0, d, 64), n1 = __shfl_up(incl1, d, 64);
-        if ((int)lane >= d) { incl0 += n0; incl1 += n1; }
+        const uint32_t n0 = __shfl_up(incl, d, 64);
+        if ((int)lane >= d) incl += n0;
     }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) part ^= __shfl_xor(part, d, 64);
-    if (lane == 63u) { s->scratch[wave] = incl0; s->scratch[GTZ_WAVES + wave] = incl1; }
-    if (lane == 0u) s->scratch[2 * GTZ_WAVES + wave] = part;
-    __syncthreads(); // also: every search is done, the key tables are free
+    if (lane == 63u) s->scratch[wave] = incl;
+    if (lane == 0u) s->scratch[GTZ_MAX_WAVES + wave] = part;
+    __syncthreads(); // also: every search is done, the key tables and the cells are free
     GTZ_STAMP(4); // waiting for the slowest thread's pass 1
-    uint32_t base0 = 0, base1 = 0, tot0 = 0, tot1 = 0, member_crc = 0;
-    for (uint32_t w = 0; w < GTZ_WAVES; ++w) {
-        const uint32_t a = s->scratch[w], b = s->scratch[GTZ_WAVES + w];
-        if (w < wave) { base0 += a; base1 += b; }
-        tot0 += a;
-        tot1 += b;
-        member_crc ^= s->scratch[2 * GTZ_WAVES + w];
+    uint32_t base = 0, total = 0, member_crc = 0;
+    for (uint32_t w = 0; w < WAVES; ++w) {
+        const uint32_t a = s->scratch[w];
+        if (w < wave) base += a;
+        total += a;
+        member_crc ^= s->scratch[GTZ_MAX_WAVES + w];
     }
     const uint32_t hdr_bits = ct->hdr_nbits;
-    const uint32_t total = tot0 + tot1;
     const uint32_t body_bits = hdr_bits + total + (ct->eob & 31u);
     const uint32_t body = (body_bits + 7u) >> 3;
     const uint32_t size = body + BGZF_MEMBER_OVERHEAD;
-    if (size > GTZ_STRIDE || body >= N + 5u) { // does not fit the slot, or a stored block would be smaller
+    if (size + 8u > 4u * GTZ_IMAGE_WORDS || body >= N + 5u) { // does not fit the image, or a stored block would be smaller
         if (tid == 0) p.fast[m] = 0;
         return;
     }
@@ -563,7 +611,7 @@ __global__ __launch_bounds__(GTZ_THREADS) void gtz_encode(const GtzParams p)
     GTZ_STAMP(5);
     // ---- pass 2: the member image in LDS ----
     const uint32_t image_words = (size + 3u) >> 2;
-    for (uint32_t t = tid; t < image_words; t += GTZ_THREADS) s->image[t] = 0;
+    for (uint32_t t = tid; t < image_words + 1u; t += THREADS) s->image[t] = 0;
     __syncthreads();
     if (tid < 18) {
         const uint8_t h[18] = {0x1F, 0x8B, 8, 4, 0, 0, 0, 0, 0, 0xFF, 6, 0, 0x42, 0x43, 2, 0,
@@ -581,18 +629,16 @@ __global__ __launch_bounds__(GTZ_THREADS) void gtz_encode(const GtzParams p)
         atomicOr(&s->image[(BIT0 >> 5) + tid], v << (BIT0 & 31u));
         atomicOr(&s->image[(BIT0 >> 5) + tid + 1u], v >> (32u - (BIT0 & 31u)));
     }
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-        const uint32_t i = it_row[u];
-        if (i == 0xFFFFFFFFu) continue;
-        const uint32_t start = BIT0 + hdr_bits + (u == 0 ? base0 + incl0 - bits[0] : tot0 + base1 + incl1 - bits[1]);
-        if (it_span[u]) {
+    if (it_row != 0xFFFFFFFFu) {
+        const uint32_t start = BIT0 + hdr_bits + base + incl - bits;
+        if (it_span) {
             GtzEmit e{s, 0, start & 31u, start >> 5};
-            for (int32_t pos = s->span_lo[i]; pos < s->span_hi[i]; ++pos) e.lit(gtz_text_byte(p, s, m_row, i, pos));
+            const uint32_t i = it_row;
+            for (int32_t pos = s->span_lo[i]; pos < s->span_hi[i]; ++pos) e.lit(s->span_bytes[i * GTZ_SPAN_MAX + (uint32_t)(pos - s->span_lo[i])]);
             e.flush();
         } else {
             GtzBitEmit e{s->image, s->gap(), s->len4(), s->dist(), {s->lit()['0'], s->lit()['1'], s->lit()['/'], s->lit()['\t']}, start};
-            if (DNAF_GTZ_EXP != 2) gtz_walk(ch[u], evs[u], it_far[u], e);
+            if (DNAF_GTZ_EXP != 2) gtz_walk(ch, evs, e);
         }
     }
     if (tid == 0) {
@@ -608,7 +654,7 @@ __global__ __launch_bounds__(GTZ_THREADS) void gtz_encode(const GtzParams p)
     GTZ_STAMP(7); // waiting for the slowest thread's emission
     uint4* dst = reinterpret_cast<uint4*>(p.stage + (uint64_t)m * GTZ_STRIDE);
     const uint4* src = reinterpret_cast<const uint4*>(s->image);
-    for (uint32_t t = tid; t < (size + 15u) >> 4; t += GTZ_THREADS) dst[t] = src[t];
+    for (uint32_t t = tid; t < (size + 15u) >> 4; t += THREADS) dst[t] = src[t];
     GTZ_STAMP(8); // copy to the staging slot
 }
 

@@ -33,19 +33,49 @@ __device__ __forceinline__ GtzMask gtz_range(uint32_t a, uint32_t b)
     return m;
 }
 
-// What the search leaves for the walks: the far matches' first alleles and the alleles that are events of their
-// own.  The far list (LDS) holds (first cell - j0) | cells << 6 | distance in bytes << 13, in order.
+// The far matches' distances, 16 bits each, in registers: a queue filled by the search (entry n at bits 16 n) and
+// drained from the bottom by the walks (each walk takes a copy).  Keeping the matches out of LDS is what lets seven
+// workgroups share a CU instead of four; the encoder is bound by latency, not by instruction issue.
+struct GtzFarQueue {
+    uint32_t w[GTZ_MAX_FAR / 2];
+    __device__ __forceinline__ void clear()
+    {
+#pragma unroll
+        for (int r = 0; r < (int)(GTZ_MAX_FAR / 2); ++r) w[r] = 0;
+    }
+    __device__ __forceinline__ void push(uint32_t n, uint32_t d) // d <= 32768
+    {
+        const uint32_t v = d << (16u * (n & 1u));
+#pragma unroll
+        for (int r = 0; r < (int)(GTZ_MAX_FAR / 2); ++r) w[r] |= (n >> 1) == (uint32_t)r ? v : 0u;
+    }
+    __device__ __forceinline__ uint32_t pop()
+    {
+        const uint32_t d = w[0] & 0xFFFFu;
+#pragma unroll
+        for (int r = 0; r + 1 < (int)(GTZ_MAX_FAR / 2); ++r) w[r] = __builtin_amdgcn_alignbit(w[r + 1], w[r], 16);
+        w[GTZ_MAX_FAR / 2 - 1] >>= 16;
+        return d;
+    }
+};
+
+// What the search leaves for the walks, all in registers: the alleles that are events, which of them begin a far
+// match, where the far matches end (cell e at bit 2 e; a match that ends with the chunk's 64th cell has no bit), and
+// the matches' distances in order.
 struct GtzEvents {
-    GtzMask ev;  // events: breaking alleles outside far matches, first alleles of far matches, forced literals
-    GtzMask far; // subset: first allele of each far match
+    GtzMask ev;   // events: breaking alleles outside far matches, first alleles of far matches, forced literals
+    GtzMask far;  // subset: first allele of each far match
+    GtzMask ends; // bit 2 e for every cell e < 64 at which a far match ends
+    GtzFarQueue dist;
 };
 
 
 // LZ77 matches of one chunk (see gtz_kernels.hip.h) and the chunk's event masks.  Lanes step from break to break
 // together; a break is only looked up when the 16 cells from it hold at least GTZ_MIN_BREAKS differing alleles.
-__device__ __forceinline__ GtzEvents gtz_find_matches(GtzShared* s, uint32_t i, uint32_t c64, const GtzChunk& c, uint32_t* farlist, bool search)
+__device__ __forceinline__ GtzEvents gtz_find_matches(GtzShared* s, uint32_t i, uint32_t c64, const GtzChunk& c, bool search)
 {
     GtzEvents E;
+    E.dist.clear();
     const GtzMask valid = gtz_range(2u * c.j0, 2u * c.j1);
     E.ev.lo = c.xlo & valid.lo;
     E.ev.hi = c.xhi & valid.hi;
@@ -54,9 +84,7 @@ __device__ __forceinline__ GtzEvents gtz_find_matches(GtzShared* s, uint32_t i, 
     uint32_t nfar = 0;
     if (search && c.j1 >= GTZ_KEY_CELLS + c.j0) {
         const uint32_t gbase = 16u * s->gw[i] - 16u * s->kw0[i] + 64u * c64; // g of the chunk's cell 0
-        const uint32_t grow = 16u * s->gw[i];                                // first g of this row
-        const uint32_t gmin = grow + (s->kb[i] & 15u);                       // first g of this row that lies in the member
-        const int32_t cs = s->cs[i];
+        const int32_t delta_i = s->row[i].delta;
         const uint64_t blo = (c.xlo | (c.xlo >> 1)) & 0x5555555555555555ull;
         const uint64_t bhi = (c.xhi | (c.xhi >> 1)) & 0x5555555555555555ull;
         const uint32_t last = c.j1 - GTZ_KEY_CELLS; // last cell a match can start at
@@ -70,62 +98,49 @@ __device__ __forceinline__ GtzEvents gtz_find_matches(GtzShared* s, uint32_t i, 
             const uint32_t g = gbase + j;
             const uint32_t dw = c.window(j);
             const uint32_t key = dw & (GTZ_KEYS - 1u);
-            const uint32_t q = min(g >> GTZ_SEG_SHIFT, GTZ_SEGS - 1u);
+            const uint32_t q = gtz_segment(g);
             // candidates: earliest in this quarter, latest / earliest in the one before, latest two back
             uint32_t cand[GTZ_CANDS];
             cand[0] = s->tab16[(2u * q) * GTZ_KEYS + key]; // 0xFFFF (none) is never below g
             cand[1] = q ? (uint32_t)s->tab16[(2u * (q - 1u) + 1u) * GTZ_KEYS + key] - 1u : 0xFFFFFFFFu;
-            if (GTZ_CANDS > 2) cand[2] = q ? (uint32_t)s->tab16[(2u * (q - 1u)) * GTZ_KEYS + key] : 0xFFFFFFFFu;
-            if (GTZ_CANDS > 3) cand[3] = q > 1u ? (uint32_t)s->tab16[(2u * (q - 2u) + 1u) * GTZ_KEYS + key] - 1u : 0xFFFFFFFFu;
+#if DNAF_GTZ_CANDS > 2
+            cand[2] = q ? (uint32_t)s->tab16[(2u * (q - 1u)) * GTZ_KEYS + key] : 0xFFFFFFFFu;
+            if (cand[2] == cand[1]) cand[2] = 0xFFFFFFFFu; // one occurrence in that quarter: same position twice
+#endif
+#if DNAF_GTZ_CANDS > 3
+            cand[3] = q > 1u ? (uint32_t)s->tab16[(2u * (q - 2u) + 1u) * GTZ_KEYS + key] - 1u : 0xFFFFFFFFu;
+#endif
             const uint32_t room = c.j1 - j;
-            bool ok[GTZ_CANDS], other_row = false;
-            uint32_t sg[GTZ_CANDS], n[GTZ_CANDS], lim[GTZ_CANDS], d[GTZ_CANDS];
+            // Every candidate alike, in this row or an earlier one: the row of the source from the word map, its bounds
+            // in the member and the byte distance from the rows' offsets (byte of position g = 4 g + delta[row]).  The
+            // tables hold unverified positions (padding between rows, cells in front of the member): the bounds reject them.
+            uint32_t f = 0, dbytes = 0, fsrc = 0, flim = 0;
 #pragma unroll
             for (int t = 0; t < (int)GTZ_CANDS; ++t) {
-                ok[t] = cand[t] < g;
-                if (t == 2 && ok[2] && cand[2] == cand[1]) ok[2] = false; // one occurrence in that quarter: same position twice
-                sg[t] = ok[t] ? cand[t] : g; // a disabled candidate reads its own position
-                other_row |= ok[t] && sg[t] < gmin;
+                const bool before = cand[t] < g;
+                const uint32_t sg = before ? cand[t] : g; // a disabled candidate reads its own position
+                const GtzRowInfo ri = s->row[s->rowmap[sg >> 4]];
+                const uint32_t x = gtz_window(s->cells, sg) ^ dw;
+                const uint32_t n = x ? (uint32_t)__builtin_ctz(x) >> 1 : 16u;
+                const uint32_t lim = min(room, ri.gend - sg); // (only used when sg < gend)
+                const uint32_t d = 4u * (g - sg) + (uint32_t)(delta_i - ri.delta);
+                const bool ok = before && sg >= ri.gfirst && sg < ri.gend && d <= 32768u;
+                const uint32_t nt = ok ? min(n, lim) : 0u;
+                if (nt > f || (nt == f && nt && d < dbytes)) { f = nt; dbytes = d; fsrc = sg; flim = lim; } // ties: the nearer one
             }
-#pragma unroll
-            for (int t = 0; t < (int)GTZ_CANDS; ++t) {
-                const uint32_t xw0 = gtz_window(s->cells, sg[t]) ^ dw;
-                n[t] = xw0 ? (uint32_t)__builtin_ctz(xw0) >> 1 : 16u;
-                lim[t] = room;
-                d[t] = 4u * (g - sg[t]);
-            }
-            if (other_row) { // a source in an earlier row of the member: its own byte distance and end
-#pragma unroll
-                for (int t = 0; t < (int)GTZ_CANDS; ++t) {
-                    if (!ok[t] || sg[t] >= gmin) continue;
-                    uint32_t r = i;
-                    while (r && 16u * s->gw[r] > sg[t]) --r;
-                    const uint32_t ks = sg[t] - 16u * s->gw[r] + 16u * s->kw0[r];
-                    // the source must lie in the member's part of that row: cells [kb, ke)
-                    if (r == i || ks < s->kb[r] || ks >= s->ke[r]) { ok[t] = false; continue; }
-                    d[t] = (uint32_t)(cs + 4 * (int32_t)(64u * c64 + j) - (s->cs[r] + 4 * (int32_t)ks));
-                    lim[t] = min(room, s->ke[r] - ks);
+            // longer than one window: keep comparing (rare except in sparse rows); only the candidate chosen on the first 16 cells
+            if (f == 16u)
+                while (f < flim) {
+                    const uint32_t x = c.window(j + f) ^ gtz_window(s->cells, fsrc + f);
+                    if (x) { f = min(flim, f + ((uint32_t)__builtin_ctz(x) >> 1)); break; }
+                    f = min(flim, f + 16u);
                 }
-            }
-            uint32_t f = 0, dbytes = 0;
-#pragma unroll
-            for (int t = 0; t < (int)GTZ_CANDS; ++t) {
-                // longer than one window: keep comparing (rare except in sparse rows)
-                if (ok[t] && n[t] == 16u)
-                    while (n[t] < lim[t]) {
-                        const uint32_t x = c.window(j + n[t]) ^ gtz_window(s->cells, sg[t] + n[t]);
-                        if (x) { n[t] += (uint32_t)__builtin_ctz(x) >> 1; break; }
-                        n[t] += 16u;
-                    }
-                const uint32_t nt = (ok[t] && d[t] <= 32768u) ? min(n[t], lim[t]) : 0u;
-                if (nt > f || (nt == f && nt && d[t] < dbytes)) { f = nt; dbytes = d[t]; } // ties: the nearer one
-            }
             bool take = f >= GTZ_KEY_CELLS;
             if (take) {
                 const GtzMask m = gtz_range(2u * j, 2u * (j + f));
                 take = (uint32_t)(__builtin_popcountll(c.xlo & m.lo) + __builtin_popcountll(c.xhi & m.hi)) >= GTZ_MIN_BREAKS;
                 if (take) {
-                    farlist[nfar++] = (j - c.j0) | (f << 6) | (dbytes << 13);
+                    E.dist.push(nfar++, dbytes);
                     E.ev.lo &= ~m.lo;
                     E.ev.hi &= ~m.hi;
                     if (j < 32u) E.far.lo |= 1ull << (2u * j); else E.far.hi |= 1ull << (2u * j - 64u);
@@ -136,7 +151,6 @@ __device__ __forceinline__ GtzEvents gtz_find_matches(GtzShared* s, uint32_t i, 
             pos = take ? j + f : j + 1u;
         }
     }
-    if (nfar < GTZ_MAX_FAR) farlist[nfar] = 0; // terminator: a recorded match has cells != 0
     // forced literals: allele a at the start of a run that allele b of the same cell cuts to two bytes
     uint64_t starts_lo = ends_lo, starts_hi = ends_hi;
     {
@@ -147,6 +161,8 @@ __device__ __forceinline__ GtzEvents gtz_find_matches(GtzShared* s, uint32_t i, 
     E.ev.hi |= (E.ev.hi >> 1) & starts_hi & valid.hi;
     E.ev.lo |= E.far.lo;
     E.ev.hi |= E.far.hi;
+    E.ends.lo = ends_lo;
+    E.ends.hi = ends_hi;
     return E;
 }
 
@@ -237,11 +253,12 @@ struct GtzBitEmit {
 
 // Visit the chunk's events in byte order.
 template <class Sink>
-__device__ __forceinline__ void gtz_walk(const GtzChunk& c, const GtzEvents& E, const uint32_t* farlist, Sink& sink)
+__device__ __forceinline__ void gtz_walk(const GtzChunk& c, const GtzEvents& E, Sink& sink)
 {
     uint32_t at = 4u * c.j0; // chunk byte at which the current gap begins
-    uint32_t nfar = 0;
     GtzMask ev = E.ev;
+    GtzFarQueue dq = E.dist;
+    uint64_t ends_lo = E.ends.lo, ends_hi = E.ends.hi;
     if (c.head && !((c.j0 < 32u ? E.far.lo >> (2u * c.j0) : E.far.hi >> (2u * c.j0 - 64u)) & 1ull)) {
         // the first cell of a row's region has nothing before it in the member to repeat: four literals
         const uint32_t code = c.code(c.j0);
@@ -264,11 +281,13 @@ __device__ __forceinline__ void gtz_walk(const GtzChunk& c, const GtzEvents& E, 
             const uint32_t byte = 2u * (64u * (uint32_t)h + b);
             const uint32_t L = byte - at;
             if ((F >> b) & 1ull) {
-                const uint32_t e = farlist[nfar++];
-                const uint32_t f = (e >> 6) & 127u;
+                // the match ends at the first end mark not yet used (none left: at the chunk's 64th cell)
+                uint32_t e2 = 128u;
+                if (ends_lo) { e2 = (uint32_t)__builtin_ctzll(ends_lo); ends_lo &= ends_lo - 1ull; }
+                else if (ends_hi) { e2 = 64u + (uint32_t)__builtin_ctzll(ends_hi); ends_hi &= ends_hi - 1ull; }
                 sink.gap_only(L, at);
-                sink.far(f, e >> 13);
-                at = byte + 4u * f;
+                sink.far((2u * e2 - byte) >> 2, dq.pop());
+                at = 2u * e2;
             } else {
                 sink.gap_lit(L, at, (uint32_t)(V >> b) & 1u);
                 at = byte + 1u;

@@ -213,13 +213,15 @@ def _gtz_tables(capi, hist):
     capi.lib.dnaf_gtz_tables_from_histogram(capi.ptr(h), None, 0, ctypes.byref(size))
     blob = np.zeros(size.value // 4, dtype=np.uint32)
     assert capi.lib.dnaf_gtz_tables_from_histogram(capi.ptr(h), capi.ptr(blob), size.value, ctypes.byref(size)) == 0
-    per = 256 + 256 + 32 + 2 + 64 + 8  # lit, len, dist, eob + hdr_nbits, hdr, two pairs of u64 nibble tables
+    # lit, len, dist, eob + hdr_nbits, hdr, two pairs of u64 nibble tables, gap table (2 x 264), len4 (72), unit_ok, pad to 8 bytes
+    per = 256 + 256 + 32 + 2 + 64 + 8 + 528 + 72 + 2
     classes = []
     for c in range(8):
         b = blob[c * per: (c + 1) * per]
         nib = b[610:618].view(np.uint64)
         classes.append({"lit": b[0:256], "len": b[256:512], "dist": b[512:544], "eob": int(b[544]), "hdr_nbits": int(b[545]),
-                        "hdr": b[546:610], "len_nb": nib[0:2], "dist_nb": nib[2:4]})
+                        "hdr": b[546:610], "len_nb": nib[0:2], "dist_nb": nib[2:4], "gap": b[618:1146].reshape(2, 264), "len4": b[1146:1218],
+                        "unit_ok": int(b[1218])})
     rest = blob[8 * per:]
     t = {"cls": classes, "crc_table": rest[0:256], "crc_base": rest[256:321], "unit_a": rest[321:385], "unit_b": rest[385:449],
          "shift_chunk": rest[449:1473], "shift_byte": rest[1473:1729]}
@@ -266,6 +268,27 @@ def test_gtz_tables_make_valid_deflate_streams(capi):
             bits.n += eb
             data.append(ord("1"))
             bits.put_entry(k["lit"][ord("1")])
+        # the walk's units (gtz_tokens.hip.h): a gap of L repeating bytes is one table entry -- a match at distance 4 for L >= 3,
+        # the separator's literal for L = 1 ('/' in half 0, tab in half 1), nothing for L = 0 -- and a far match of f cells
+        # takes its length code from len4[f]
+        assert k["unit_ok"] == 1
+        for half, sep in ((0, ord("/")), (1, ord("\t"))):
+            for L in range(0, 257):
+                if L == 2:
+                    continue
+                entry = int(k["gap"][half][L])
+                assert (entry & 31) + max(int(k["lit"][ord("0")]) & 31, int(k["lit"][ord("1")]) & 31) <= 32
+                bits.put_entry(entry)
+                if L == 1:
+                    data.append(sep)
+                else:
+                    for _ in range(L):
+                        data.append(data[-4])
+                assert (L == 0) == (entry == 0)
+                data.append(ord("0"))
+                bits.put_entry(k["lit"][ord("0")])
+        for f in range(1, 65):
+            assert int(k["len4"][f]) == int(k["len"][4 * f - 3])
         bits.put_entry(k["eob"])
         assert zlib.decompressobj(-15).decompress(bits.bytes()) == bytes(data), "class %d" % c
         assert k["hdr_nbits"] < 700  # run-length coded: far below the 1338 bits of a flat 4-bit listing
