@@ -290,16 +290,15 @@ __device__ unsigned long long gtz_prof[16];
 #define GTZ_STAMP(k) do { } while (0)
 #endif
 
-#ifndef DNAF_GTZ_BREAK_KEYS
-#define DNAF_GTZ_BREAK_KEYS 0 // key tables hold only positions whose cell differs from the cell before
-#endif
-#ifndef DNAF_GTZ_TAB2
-#define DNAF_GTZ_TAB2 0 // key tables by two sweeps of plain stores instead of one with a read
-#endif
 #ifndef DNAF_GTZ_EXP
 #define DNAF_GTZ_EXP 0 // timing experiments (output invalid): 1 no search, 2 no emission walk, 3 no count walk, 4 no key tables, 5 no CRC
 #endif
-#ifdef DNAF_GTZ_WAVES_PER_EU
+// The encoder is bound by latency (LDS round trips, dependent bit scans), not by instruction issue: seven workgroups per CU
+// (LDS: 22.8 KB each) with 72 registers and a few spills beat five with 88 (profiles/r03_gtz_occupancy.txt).
+#ifndef DNAF_GTZ_WAVES_PER_EU
+#define DNAF_GTZ_WAVES_PER_EU 7
+#endif
+#if DNAF_GTZ_WAVES_PER_EU
 #define GTZ_OCCUPANCY __attribute__((amdgpu_waves_per_eu(DNAF_GTZ_WAVES_PER_EU, 8)))
 #else
 #define GTZ_OCCUPANCY
@@ -443,14 +442,13 @@ __global__ __launch_bounds__(THREADS) GTZ_OCCUPANCY void gtz_encode(const GtzPar
         return;
     }
     GTZ_STAMP(1); // cells and code tables in LDS
-    // Key tables: for every quarter of the g space the earliest and the latest position of every 5-cell key, 16-bit
-    // entries.  No atomics and no validity tests: the threads sweep a quarter in ascending order, 256 consecutive
-    // positions per step -- "latest" is a plain store (the last step that holds the key wins), "earliest" a store where
-    // the entry is still empty.  Waves drift apart by a step or two and lanes of one step race, so both are
-    // approximate (some occurrence near the end / the beginning); the search verifies whatever it finds against the
-    // cells themselves and against the bounds of the source's row, so any position that is entered is harmless.
-    // Only positions whose cell differs from the cell before are entered (DNAF_GTZ_BREAK_KEYS): the search looks keys
-    // up at such positions only, and the long stretches of "0/0" stay away from the tables.
+    // Key tables: for every segment of the g space the earliest and the latest position of every 5-cell key, 16-bit
+    // entries.  No atomics and no validity tests: the threads sweep the g space in ascending order -- "latest" is a plain
+    // store (the last step that holds the key wins), "earliest" a store where the entry is still empty.  Waves drift
+    // apart by a step or two and lanes of one step race, so both are approximate (some occurrence near the end / the
+    // beginning); the search verifies whatever it finds against the cells themselves and against the bounds of the
+    // source's row, so any position that is entered is harmless.  (Entering only positions whose cell differs from the
+    // cell before -- the only ones the search looks up -- was measured: slower and 1 % more bytes.)
     {
         for (uint32_t t = tid; t < (2 * GTZ_SEGS - 1) * GTZ_KEYS / 2; t += THREADS) { // [quarter][earliest, latest + 1][key], two entries per word
             const uint32_t which = (t / (GTZ_KEYS / 2u)) & 1u;
@@ -458,38 +456,31 @@ __global__ __launch_bounds__(THREADS) GTZ_OCCUPANCY void gtz_encode(const GtzPar
         }
         __syncthreads();
         const uint32_t total = DNAF_GTZ_EXP == 4 ? 0u : 16u * s->gw[nr];
-#if DNAF_GTZ_TAB2
-        // two sweeps of plain stores, no read in between: ascending for "latest", descending for "earliest"
-        const uint32_t steps = (total + THREADS - 1u) / THREADS;
-        for (uint32_t st = 0; st < steps; ++st) {
-            const uint32_t g = st * THREADS + tid;
-            const uint32_t gd = (steps - 1u - st) * THREADS + tid;
-            if (g < total) {
-                const uint32_t q = gtz_segment(g);
-                if (q + 1u < GTZ_SEGS) s->tab16[(2u * q + 1u) * GTZ_KEYS + (gtz_window(s->cells, g) & (GTZ_KEYS - 1u))] = (uint16_t)(g + 1u);
-            }
-            if (gd < total) {
-                const uint32_t q = gtz_segment(gd);
-                s->tab16[(2u * q) * GTZ_KEYS + (gtz_window(s->cells, gd) & (GTZ_KEYS - 1u))] = (uint16_t)gd;
-            }
-        }
-#else
-        for (uint32_t g = tid; g < total; g += THREADS) {
-            const uint32_t q = gtz_segment(g);
-            uint32_t key;
-            bool enter = true;
-            if (DNAF_GTZ_BREAK_KEYS && g) {
-                const uint32_t w = gtz_window(s->cells, g - 1u);
-                key = (w >> 2) & (GTZ_KEYS - 1u);
-                enter = ((w ^ (w >> 2)) & 3u) != 0u;
-            } else key = gtz_window(s->cells, g) & (GTZ_KEYS - 1u);
-            if (enter) {
-                uint16_t* e = &s->tab16[(2u * q) * GTZ_KEYS + key];
-                if (*e == 0xFFFFu) *e = (uint16_t)g;
-                if (q + 1u < GTZ_SEGS) e[GTZ_KEYS] = (uint16_t)(g + 1u);
+        // Every segment is swept by its own wave(s), in ascending steps of 256 positions, four consecutive ones per lane
+        // (one window read gives their keys; the four "earliest" entries are read together): a table has one writer in
+        // program order, so "latest" and "earliest" are exact to the 256 positions of a step, whatever the waves' pace.
+        {
+            constexpr uint32_t WPS = WAVES / GTZ_SEGS ? WAVES / GTZ_SEGS : 1u; // waves per segment (256 threads, 3 segments: one, the fourth wave rests)
+            const uint32_t wave_ = tid >> 6, lane_ = tid & 63u;
+            const uint32_t q = wave_ / WPS, sub = wave_ - q * WPS;
+            if (q < GTZ_SEGS) {
+                const uint32_t seg_lo = q * GTZ_SEG_CELLS, seg_hi = q + 1u < GTZ_SEGS ? min(total, seg_lo + GTZ_SEG_CELLS) : total;
+                uint16_t* tab = &s->tab16[(2u * q) * GTZ_KEYS];
+                for (uint32_t g0 = seg_lo + 256u * sub + 4u * lane_; g0 < seg_hi; g0 += 256u * WPS) {
+                    const uint32_t w = gtz_window(s->cells, g0);
+                    uint32_t key[4], seen[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) { key[k] = (w >> (2 * k)) & (GTZ_KEYS - 1u); seen[k] = tab[key[k]]; }
+#pragma unroll
+                    for (int k = 3; k >= 0; --k) // descending: of equal keys in this group the lowest position stays
+                        if (seen[k] == 0xFFFFu) tab[key[k]] = (uint16_t)(g0 + (uint32_t)k);
+                    if (q + 1u < GTZ_SEGS) {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) tab[GTZ_KEYS + key[k]] = (uint16_t)(g0 + (uint32_t)k + 1u);
+                    }
+                }
             }
         }
-#endif
         __syncthreads();
     }
 
