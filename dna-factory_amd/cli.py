@@ -139,6 +139,87 @@ def _generate_shard(device, seed, rng, mt_state, st, tb, row_lo, row_hi, rng_row
             pending.result()
 
 
+def _write_round_robin(path, header, st, tb, seed, rng, devices, compresslevel, tile_rows, threads, host_bgzf, mt_state, bed_path, progress):
+    """Tile k of the table goes to device k mod G; the calling thread writes the tiles' BGZF members (and .bed rows) in
+    order as they arrive.  A device works one tile ahead of the writer: the library alternates two pinned staging
+    buffers, so a device's i-th fetch reuses the buffer of its (i-2)-th; the writer acknowledges every tile it has
+    written and a device collects the acknowledgement of tile i-2 before it fetches tile i."""
+    import queue
+
+    from . import bgzf, capi
+    from .rowgen import RowGenerator
+
+    n, G = len(tb), len(devices)
+    q = 1
+    if rng == "mt19937" and len(st):
+        from math import gcd
+
+        q = 156 // gcd(len(st), 156)  # tiles start on a wave boundary of the sequential stream
+    tile_rows = max(q, tile_rows // q * q)
+    tiles = [(lo, min(n, lo + tile_rows)) for lo in range(0, n, tile_rows)]
+    tb.prefixes()  # the rows' fixed columns are formatted once; the tiles' tables are views of them
+    slots = [queue.Queue() for _ in devices]
+    acks = [threading.Semaphore(0) for _ in devices]
+    stop, written = threading.Event(), threading.Event()
+    trace = os.environ.get("DNAF_TRACE_TILES")
+
+    def produce(g):
+        try:
+            with RowGenerator(device=devices[g], seed=seed, rng=rng, mt_state=mt_state) as gen:
+                gen.set_samples(st)
+                for k in range(g, len(tiles), G):
+                    lo, hi = tiles[k]
+                    t0 = time.time()
+                    gen.set_snps(tb.slice(lo, hi), rng_row0=lo)
+                    gen.ctx.generate(0, hi - lo, capi.OUT_TEXT if host_bgzf and bed_path is None else capi.OUT_TEXT | capi.OUT_PACKED)
+                    bed = bytes(gen.ctx.export_bed()) if bed_path else None
+                    if not host_bgzf:
+                        gen.ctx.bgzf_compress(reuse_tables=k >= G)
+                    t1 = time.time()
+                    if k >= 2 * G:  # this fetch overwrites the staging buffer of this device's tile k - 2G: written by now?
+                        while not acks[g].acquire(timeout=0.5):
+                            if stop.is_set():
+                                return
+                    t2 = time.time()
+                    if host_bgzf:
+                        gen.ctx.sync()
+                        view = gen.ctx.fetch_text()
+                    else:
+                        view = gen.ctx.fetch_bgzf()
+                    slots[g].put((k, view, bed))
+                    if trace:
+                        print("tile %d on device slot %d: produced in %.3f s, waited %.3f s for the writer, copied out in %.3f s" % (k, g, t1 - t0, t2 - t1, time.time() - t2), flush=True)
+                written.wait()  # the views handed over live in this context's pinned buffers: keep it until the writer is through
+        except BaseException as e:  # surfaced in the writer, never swallowed
+            slots[g].put((-1, e, None))
+
+    ths = [threading.Thread(target=produce, args=(g,), daemon=True) for g in range(G)]
+    for t in ths:
+        t.start()
+    bed_f = open(bed_path, "wb") if bed_path else None
+    try:
+        if bed_f:
+            bed_f.write(BED_MAGIC)
+        with bgzf.BgzfWriter(path, compresslevel=compresslevel, threads=threads) as f:
+            f.write(header)
+            for k, (lo, hi) in enumerate(tiles):
+                got, view, bed = slots[k % G].get()
+                if got != k:
+                    raise view if got == -1 else RuntimeError("tile %d arrived in place of tile %d" % (got, k))
+                (f.write if host_bgzf else f.write_members)(view)
+                if bed_f:
+                    bed_f.write(bed)
+                acks[k % G].release()
+                progress(hi - lo)
+    finally:
+        stop.set()
+        written.set()
+        for t in ths:
+            t.join()
+        if bed_f:
+            bed_f.close()
+
+
 BED_MAGIC = bytes([0x6C, 0x1B, 0x01])  # PLINK 1 .bed, SNP-major
 
 
@@ -178,93 +259,15 @@ def write_vcf(path, header, st, tb, seed, rng, devices, compresslevel, tile_rows
         if bed:
             bed.close()
     else:
-        from math import gcd
-
-        from .sharding import shard_bounds
-
+        # Several devices: the reference's own shape (pop_factory.py:426-469) -- the work is dealt round-robin (there:
+        # rows to worker processes, here: tiles of rows to GPUs) and ONE writer appends the results in order.  Every
+        # byte is written once, straight into population.vcf.gz; rows keep their global RNG row, so the bytes do not
+        # depend on how many devices took part.
         if chunk_restart:
             raise SystemExit("--compat-chunk-restart is only supported on one device")
-        G = len(devices)
-        bounds = shard_bounds(n, G)
-        if rng == "mt19937" and len(st):  # shards must start on a wave boundary of the sequential stream
-            q = 156 // gcd(len(st), 156)
-            bounds = [min(n, (b + q - 1) // q * q) for b in bounds[:-1]] + [n]
-        shard_paths = ["%s.shard%d" % (path, g) for g in range(G)]
-        bed_shards = ["%s.shard%d" % (bed_path, g) for g in range(G)] if bed_path else []
-        errors = []
-
-        def run(g):
-            try:
-                with open(shard_paths[g], "wb") as raw, open(bed_shards[g] if bed_path else os.devnull, "wb") as bed:
-                    w = bgzf.BgzfWriter(fileobj=_NoClose(raw), compresslevel=compresslevel, threads=threads)
-                    if g == 0:
-                        w.write(header)
-                    if bounds[g + 1] > bounds[g]:
-                        _generate_shard(devices[g], seed, rng, mt_state, st, tb, bounds[g], bounds[g + 1], bounds[g], tile_rows, w,
-                                        progress, host_bgzf, bed if bed_path else None)
-                    w.flush()  # no EOF block inside a shard
-                    w.close_pool()
-            except BaseException as e:  # surfaced in the parent, never swallowed
-                errors.append(e)
-
-        ths = [threading.Thread(target=run, args=(g,)) for g in range(G)]
-        for t in ths:
-            t.start()
-        for t in ths:
-            t.join()
-        if errors:
-            raise errors[0]
-        with open(path, "wb") as out:
-            for sp in shard_paths:
-                _append_file(out, sp)
-                os.remove(sp)
-            out.write(bgzf.EOF_BLOCK)
-        if bed_path:
-            with open(bed_path, "wb") as out:
-                out.write(BED_MAGIC)
-                for sp in bed_shards:
-                    _append_file(out, sp)
-                    os.remove(sp)
+        _write_round_robin(path, header, st, tb, seed, rng, devices, compresslevel, tile_rows, threads, host_bgzf, mt_state,
+                           bed_path, progress)
     print("Finished VCF file output. (%.1f s)" % (time.time() - t0), flush=True)
-
-
-def _append_file(out, src_path):
-    """Append a shard file to the open binary file `out`: in the kernel where the platform allows it
-    (copy_file_range: no round trip through user space, reflink on file systems that have it)."""
-    out.flush()
-    with open(src_path, "rb") as f:
-        left = os.fstat(f.fileno()).st_size
-        try:
-            while left:
-                n = os.copy_file_range(f.fileno(), out.fileno(), min(left, 1 << 30))
-                if n == 0:
-                    break
-                left -= n
-        except (AttributeError, OSError):
-            pass
-        if left:  # whatever the kernel did not take (or everything, on platforms without copy_file_range)
-            os.lseek(out.fileno(), 0, os.SEEK_END)
-            f.seek(-left, os.SEEK_END)
-            while True:
-                chunk = f.read(8 << 20)
-                if not chunk:
-                    break
-                os.write(out.fileno(), chunk)
-    out.seek(0, os.SEEK_END)
-
-
-class _NoClose:
-    def __init__(self, f):
-        self._f = f
-
-    def write(self, b):
-        return self._f.write(b)
-
-    def flush(self):
-        self._f.flush()
-
-    def close(self):
-        pass
 
 
 def generate_population(args):

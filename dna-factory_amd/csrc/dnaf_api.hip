@@ -394,6 +394,13 @@ int dnaf_set_mt_state(dnaf_ctx* c, const uint32_t* key, uint32_t pos, uint64_t r
     return DNAF_OK;
 }
 
+int dnaf_set_rng_row0(dnaf_ctx* c, uint64_t rng_row0)
+{
+    if (!c) return DNAF_ERR_BAD_ARG;
+    c->rng_row0 = rng_row0;
+    return DNAF_OK;
+}
+
 // floor(cum * 2^53) clamped to 2^53: `cum >= r * 2^-53` <=> r <= T for the numerators r < 2^53 of numpy's doubles
 static uint64_t threshold_u53(double cum)
 {
@@ -629,9 +636,11 @@ static int mt_prepare_states(dnaf_ctx* c, uint64_t lo, uint64_t n, uint64_t D)
         HIP_TRY(c, hipMemcpy(c->d_mt_base, c->mt_key, sizeof c->mt_key, hipMemcpyHostToDevice));
     }
     const uint32_t* poly = nullptr;
-    if (c->mt_valid && lo == c->mt_lo + c->mt_n && n <= c->mt_n) {
-        // the next tile of a sequential sweep: every cached state advances by the same distance
-        if (int rc = mt_poly_for(c, c->mt_n * D * 624, &poly)) return rc;
+    if (c->mt_valid && lo > c->mt_lo && n <= c->mt_n) {
+        // a later window of the same stream -- the next tile of a sequential sweep, or of a device that takes every G-th
+        // tile of a job: every cached state advances by the same distance (one polynomial per distance, cached)
+        if (lo - c->mt_lo > 0xFFFFFFFFFFFFFFFFull / (D * 624)) return fail(c, DNAF_ERR_UNSUPPORTED, "dnaf_generate: MT19937 stream position overflows 64 bits");
+        if (int rc = mt_poly_for(c, (lo - c->mt_lo) * D * 624, &poly)) return rc;
         hipLaunchKernelGGL(dnaf::mt_jump_kernel, dim3((uint32_t)c->mt_n), dim3(640), 0, c->stream, (const uint32_t*)c->d_mt_states,
                            (const uint32_t*)nullptr, c->d_mt_tmp, poly);
         HIP_TRY(c, hipGetLastError());

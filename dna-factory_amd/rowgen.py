@@ -30,11 +30,16 @@ class RowGenerator:
         self.seed = int(seed)
         self.rng = rng
         self.mt_state = None if mt_state is None else (np.array(mt_state[0], dtype=np.uint32), int(mt_state[1]))
+        self._rng_is_set = False
         self._set_rng(0)
         self.n_samples = None
         self.n_rows = None
 
     def _set_rng(self, rng_row0):
+        if self._rng_is_set:  # mode, seed / state are this generator's for life: later tables only move the RNG row
+            self.ctx.set_rng_row0(rng_row0)
+            return
+        self._rng_is_set = True
         if self.mt_state is not None:
             self.ctx.set_mt_state(self.mt_state[0], self.mt_state[1], rng_row0)
         else:

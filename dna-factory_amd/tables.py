@@ -102,8 +102,17 @@ class SnpTable:
                         self.n_alleles[order], self.cum[order])
 
     def slice(self, begin, end):
-        return SnpTable(self.snp_id[begin:end], self.chrom[begin:end], self.position[begin:end], self.ref[begin:end],
-                        self.alt[begin:end], self.n_alleles[begin:end], self.cum[begin:end])
+        t = SnpTable(self.snp_id[begin:end], self.chrom[begin:end], self.position[begin:end], self.ref[begin:end],
+                     self.alt[begin:end], self.n_alleles[begin:end], self.cum[begin:end])
+        if self._prefix is not None:  # the formatted fixed columns go along (tiles of a table that was formatted once)
+            blob, off = self._prefix
+            begin, end = max(0, min(begin, len(self))), max(0, min(end, len(self)))
+            if end > begin:
+                o = off[begin:end + 1]
+                t._prefix = (blob[int(o[0]):int(o[-1])], o - o[0])
+        if self._class is not None:
+            t._class = self._class[begin:end]
+        return t
 
 
 def _key_matches_int(k):

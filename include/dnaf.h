@@ -107,6 +107,13 @@ int dnaf_set_rng(dnaf_ctx* ctx, uint32_t mode, uint64_t seed, uint64_t rng_row0)
  * numpy calls continues the very same stream. */
 int dnaf_set_mt_state(dnaf_ctx* ctx, const uint32_t* key, uint32_t pos, uint64_t rng_row0);
 
+/* Only the RNG row of table row 0 changes; mode, seed / generator state and whatever the library has derived from
+ * them stay (in MT19937 mode: the cached block states, which a later window of the same stream is reached from by
+ * one jump per wave).  For a context that is handed the tiles of a larger job one table at a time -- the way the
+ * reference deals rows to its workers, stripe_list common/snp.py:82-88, pop_factory.py:426: here tile k of the job
+ * goes to device k mod G. */
+int dnaf_set_rng_row0(dnaf_ctx* ctx, uint64_t rng_row0);
+
 /* Upload the SNP table (the work_q argument, pop_factory.py:474) and lay out
  * the output: per-row integer thresholds, forced slot, text offsets. */
 int dnaf_set_snps(dnaf_ctx* ctx, const dnaf_snp_table* table);

@@ -148,22 +148,20 @@ def test_random_choice_replay_leaves_python_random_in_step(pop):
         assert random.getstate() == after
 
 
-def test_shard_files_are_appended_in_order(tmp_path):
-    """cli._append_file (kernel-side copy where available) leaves the destination positioned at its end, so that
-    header || shard 0 || shard 1 || EOF block comes out in order."""
-    from dna_factory_amd import cli
+def test_table_slices_carry_the_formatted_columns():
+    """SnpTable.slice of a table whose fixed columns were formatted once (the multi-device writer formats the job's table
+    once and hands every device views of its tiles): the same bytes and offsets as formatting the slice itself."""
+    from dna_factory_amd import genome
 
-    rs = np.random.RandomState(3)
-    parts = [rs.randint(0, 256, n).astype(np.uint8).tobytes() for n in (5 << 20, 1, 0, 70000)]
-    for k, blob in enumerate(parts):
-        (tmp_path / ("shard%d" % k)).write_bytes(blob)
-    out_path = tmp_path / "joined"
-    with open(out_path, "wb") as out:
-        out.write(b"header")
-        for k in range(len(parts)):
-            cli._append_file(out, str(tmp_path / ("shard%d" % k)))
-        out.write(b"EOF")
-    assert out_path.read_bytes() == b"header" + b"".join(parts) + b"EOF"
+    tb = genome.synthetic_snp_table(5000, 0.01, np.random.RandomState(8))
+    blob, off = tb.prefixes()
+    for lo, hi in ((0, 5000), (0, 1), (17, 2048), (4999, 5000), (1234, 1234)):
+        t = tb.slice(lo, hi)
+        fresh = genome.synthetic_snp_table(5000, 0.01, np.random.RandomState(8)).slice(lo, hi)
+        b1, o1 = t.prefixes()
+        b2, o2 = fresh.prefixes()
+        assert bytes(b1) == bytes(b2) and list(o1) == list(o2)
+        assert (t.chrom_class == fresh.chrom_class).all()
 
 
 def test_numpy_legacy_choice_replay_is_numpy():
