@@ -33,7 +33,7 @@ SYMBOLS = [
     "dnaf_reserve_output",
     "dnaf_sync", "dnaf_last_generate_ms", "dnaf_timing_begin", "dnaf_timing_end", "dnaf_read_text", "dnaf_read_packed", "dnaf_device_buffers",
     "dnaf_format_prefixes", "dnaf_bgzf_compress", "dnaf_read_bgzf", "dnaf_last_bgzf_ms",
-    "dnaf_bgzf_tables_from_histogram", "dnaf_gtz_tables_from_histogram", "dnaf_set_mt_state", "dnaf_set_rng_row0", "dnaf_mt_jump_host", "dnaf_mt_characteristic_polynomial",
+    "dnaf_bgzf_tables_from_histogram", "dnaf_gtz_tables_from_histogram", "dnaf_set_mt_state", "dnaf_set_rng_row0", "dnaf_set_rng_divisor", "dnaf_mt_jump_host", "dnaf_mt_characteristic_polynomial",
     "dnaf_fetch_bgzf", "dnaf_fetch_text", "dnaf_read_text_range", "dnaf_format_snps_json", "dnaf_parse_snps_json",
     "dnaf_allele_counts", "dnaf_export_bed", "dnaf_read_bed", "dnaf_packed_pitch_words", "dnaf_numpy_legacy_choice",
 ]
@@ -106,6 +106,7 @@ def _load():
         "dnaf_gtz_tables_from_histogram": (ci, [vp, vp, u64, vp]),
         "dnaf_set_mt_state": (ci, [vp, vp, u32, u64]),
         "dnaf_set_rng_row0": (ci, [vp, u64]),
+        "dnaf_set_rng_divisor": (ci, [vp, u32]),
         "dnaf_fetch_bgzf": (ci, [vp, vp, vp]),
         "dnaf_fetch_text": (ci, [vp, vp, vp]),
         "dnaf_read_text_range": (ci, [vp, u64, u64, vp]),
@@ -294,6 +295,10 @@ class Context:
     def set_rng_row0(self, rng_row0):
         """Only the RNG row of table row 0 changes (the next tile of a larger job); mode, seed and cached state stay."""
         self._check(lib.dnaf_set_rng_row0(self._h, int(rng_row0)))
+
+    def set_rng_divisor(self, n):
+        """Table rows k n .. k n + n - 1 share RNG row k: the stream of the reference's `-n n` forked workers."""
+        self._check(lib.dnaf_set_rng_divisor(self._h, int(n)))
 
     def set_snps(self, snp_id, chrom_class, n_alleles, cum_freq, prefix_bytes, prefix_off):
         n = len(snp_id)

@@ -63,6 +63,11 @@ def parse_cmd_args(args):
     p.add_argument("--compat-chunk-restart", action="store_true",
                    help="restart the random stream at every 1M-SNP work chunk like the reference does "
                         "(pop_factory.py:402-411; only matters from 2M SNPs up)")
+    p.add_argument("--compat-workers", action="store_true",
+                   help="reproduce what the reference's -n N does to the random stream: its N forked workers all draw the "
+                        "parent's stream, so rows kN+1 .. kN+N of a work chunk are made from the same uniforms "
+                        "(pop_factory.py:426-434); N is taken from -n (default 2, like the reference); implies "
+                        "--compat-chunk-restart")
     p.add_argument("--compat-deleterious-file-bug", action="store_true",
                    help="keep the reference's behaviour for --deleterious_file: ids stay strings, so nothing is forced")
     return p.parse_args(args)
@@ -95,7 +100,7 @@ def reference_chunks(n):
 
 
 def _generate_shard(device, seed, rng, mt_state, st, tb, row_lo, row_hi, rng_row_lo, tile_rows, sink, progress, host_bgzf,
-                    bed_sink=None):
+                    bed_sink=None, rng_divisor=1):
     """Rows [row_lo, row_hi) of the table on one GPU -> the BGZF sink, in order.  By default the text is
     compressed on the GPU and only BGZF members cross PCIe; with host_bgzf the text is copied out and
     compressed by the sink's zlib workers."""
@@ -106,9 +111,10 @@ def _generate_shard(device, seed, rng, mt_state, st, tb, row_lo, row_hi, rng_row
 
     with RowGenerator(device=device, seed=seed, rng=rng, mt_state=mt_state) as gen, ThreadPoolExecutor(max_workers=1) as writer:
         gen.set_samples(st)
+        gen.ctx.set_rng_divisor(rng_divisor)
         gen.set_snps(tb.slice(row_lo, row_hi), rng_row0=rng_row_lo)
         n = row_hi - row_lo
-        q = gen.row_quantum
+        q = gen.row_quantum * rng_divisor  # tiles begin where a wave of the stream and a group of rows sharing a stream row begin
         tile_rows = max(q, tile_rows // q * q)
         pending = None  # the sink drains tile k on the writer thread while the GPU produces tile k+1
         trace = os.environ.get("DNAF_TRACE_TILES")  # per-tile seconds: GPU work, device -> host copy, wait for the writer
@@ -224,7 +230,7 @@ BED_MAGIC = bytes([0x6C, 0x1B, 0x01])  # PLINK 1 .bed, SNP-major
 
 
 def write_vcf(path, header, st, tb, seed, rng, devices, compresslevel, tile_rows=0, threads=0, host_bgzf=False,
-              mt_state=None, chunk_restart=False, bed_path=None):
+              mt_state=None, chunk_restart=False, bed_path=None, workers=1):
     """population.vcf.gz = header + one body line per SNP (output_vcf_population, pop_factory.py:385-415).
     With several devices each GPU writes its contiguous SNP range to its own BGZF shard; shards are then
     concatenated (BGZF members are independent), ending with a single EOF block."""
@@ -255,7 +261,9 @@ def write_vcf(path, header, st, tb, seed, rng, devices, compresslevel, tile_rows
         with bgzf.BgzfWriter(path, compresslevel=compresslevel, threads=threads) as f:
             f.write(header)
             for lo, hi, r0 in units:
-                _generate_shard(devices[0], seed, rng, mt_state, st, tb, lo, hi, r0, tile_rows, f, progress, host_bgzf, bed)
+                # the reference uses one worker for a chunk with fewer rows than workers (pop_factory.py:422-424)
+                _generate_shard(devices[0], seed, rng, mt_state, st, tb, lo, hi, r0, tile_rows, f, progress, host_bgzf, bed,
+                                rng_divisor=workers if hi - lo >= workers else 1)
         if bed:
             bed.close()
     else:
@@ -263,8 +271,8 @@ def write_vcf(path, header, st, tb, seed, rng, devices, compresslevel, tile_rows
         # rows to worker processes, here: tiles of rows to GPUs) and ONE writer appends the results in order.  Every
         # byte is written once, straight into population.vcf.gz; rows keep their global RNG row, so the bytes do not
         # depend on how many devices took part.
-        if chunk_restart:
-            raise SystemExit("--compat-chunk-restart is only supported on one device")
+        if chunk_restart or workers > 1:
+            raise SystemExit("--compat-chunk-restart / --compat-workers are only supported on one device")
         _write_round_robin(path, header, st, tb, seed, rng, devices, compresslevel, tile_rows, threads, host_bgzf, mt_state,
                            bed_path, progress)
     print("Finished VCF file output. (%.1f s)" % (time.time() - t0), flush=True)
@@ -340,7 +348,8 @@ def generate_population(args):
         mt_state = (state[1], int(state[2]))
     write_vcf(outdir + "population.vcf.gz", header, st, tb, seed, args.rng, devices, args.compression_level,
               tile_rows=args.tile_rows, threads=args.threads, host_bgzf=args.host_bgzf, mt_state=mt_state,
-              chunk_restart=args.compat_chunk_restart, bed_path=outdir + "population.bed" if args.plink else None)
+              chunk_restart=args.compat_chunk_restart or args.compat_workers, bed_path=outdir + "population.bed" if args.plink else None,
+              workers=max(1, args.num_processes) if args.compat_workers else 1)
     if args.plink:
         pop.write_bim(tb, outdir + "population.bim")
     if snps_writer is not None:

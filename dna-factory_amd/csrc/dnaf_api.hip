@@ -65,6 +65,7 @@ struct dnaf_ctx {
     // rng
     uint32_t rng_mode = DNAF_RNG_PHILOX;
     uint64_t seed = 0, rng_row0 = 0;
+    uint32_t rng_div = 1; // table rows k * rng_div .. + rng_div - 1 share RNG row k (dnaf_set_rng_divisor)
 
     // snp table
     bool have_snps = false;
@@ -401,6 +402,14 @@ int dnaf_set_rng_row0(dnaf_ctx* c, uint64_t rng_row0)
     return DNAF_OK;
 }
 
+int dnaf_set_rng_divisor(dnaf_ctx* c, uint32_t n)
+{
+    if (!c) return DNAF_ERR_BAD_ARG;
+    if (n < 1) return fail(c, DNAF_ERR_BAD_ARG, "dnaf_set_rng_divisor: n must be at least 1");
+    c->rng_div = n;
+    return DNAF_OK;
+}
+
 // floor(cum * 2^53) clamped to 2^53: `cum >= r * 2^-53` <=> r <= T for the numerators r < 2^53 of numpy's doubles
 static uint64_t threshold_u53(double cum)
 {
@@ -681,11 +690,16 @@ static int generate_mt(dnaf_ctx* c, uint64_t row_begin, uint64_t n_rows, uint32_
     const uint64_t S = c->S;
     const uint64_t R = 156 / gcd_u64(S, 156);   // rows per wave: 4*S*R is a multiple of 624
     const uint64_t D = 4 * S * R / 624;         // blocks per wave
-    const uint64_t rng_row = c->rng_row0 + row_begin;
+    const uint64_t N = c->rng_div;              // table rows that share a stream row (1 ordinarily)
+    if (row_begin % N)
+        return fail(c, DNAF_ERR_UNSUPPORTED, "dnaf_generate: with an RNG divisor of %llu a range must start on a multiple of it (row %llu does not)",
+                    (unsigned long long)N, (unsigned long long)row_begin);
+    const uint64_t rng_row = c->rng_row0 + row_begin / N;
+    const uint64_t stream_rows = (n_rows + N - 1) / N;
     if (rng_row % R)
         return fail(c, DNAF_ERR_UNSUPPORTED, "dnaf_generate: in MT19937 mode a range must start on a multiple of %llu rows "
                     "(RNG row %llu does not), so that every wave starts on a block of the stream", (unsigned long long)R, (unsigned long long)rng_row);
-    const uint64_t n_waves = (n_rows + R - 1) / R;
+    const uint64_t n_waves = (stream_rows + R - 1) / R;
     if (n_waves > 0x7FFFFFFFull) return fail(c, DNAF_ERR_UNSUPPORTED, "dnaf_generate: too many waves; generate fewer rows per call");
     if (!c->d_thr53) {
         HIP_TRY(c, hipMalloc((void**)&c->d_thr53, c->h_thr53.size() * sizeof(uint64_t) + 8));
@@ -717,6 +731,7 @@ static int generate_mt(dnaf_ctx* c, uint64_t row_begin, uint64_t n_rows, uint32_
     p.row_begin = row_begin;
     p.n_rows = n_rows;
     p.rng_row0 = c->rng_row0;
+    p.rng_div = c->rng_div;
     p.key0 = p.key1 = 0;
     p.S = c->S; p.G = c->G; p.W = c->W;
     p.nseg = 1; p.seg_groups = 64; p.rows_per_wave = 1;
@@ -725,10 +740,16 @@ static int generate_mt(dnaf_ctx* c, uint64_t row_begin, uint64_t n_rows, uint32_
     mp.start_off = c->mt_pos == 624 ? 0 : c->mt_pos;
     mp.rows_per_wave = (uint32_t)R;
     mp.wave0_row = 0;
-    const dim3 grid((uint32_t)n_waves), block(64);
-    if (what == (DNAF_OUT_TEXT | DNAF_OUT_PACKED)) hipLaunchKernelGGL((dnaf::mt_rowgen_kernel<true, true>), grid, block, 0, c->stream, mp);
-    else if (what == DNAF_OUT_TEXT) hipLaunchKernelGGL((dnaf::mt_rowgen_kernel<true, false>), grid, block, 0, c->stream, mp);
-    else hipLaunchKernelGGL((dnaf::mt_rowgen_kernel<false, true>), grid, block, 0, c->stream, mp);
+    mp.row_stride = (uint32_t)N;
+    const dim3 block(64);
+    for (uint64_t phase = 0; phase < N && phase < n_rows; ++phase) { // one launch per stripe of rows that draw the stream afresh
+        mp.row_phase = (uint32_t)phase;
+        mp.n_stream_rows = (n_rows - phase + N - 1) / N;
+        const dim3 grid((uint32_t)((mp.n_stream_rows + R - 1) / R));
+        if (what == (DNAF_OUT_TEXT | DNAF_OUT_PACKED)) hipLaunchKernelGGL((dnaf::mt_rowgen_kernel<true, true>), grid, block, 0, c->stream, mp);
+        else if (what == DNAF_OUT_TEXT) hipLaunchKernelGGL((dnaf::mt_rowgen_kernel<true, false>), grid, block, 0, c->stream, mp);
+        else hipLaunchKernelGGL((dnaf::mt_rowgen_kernel<false, true>), grid, block, 0, c->stream, mp);
+    }
     HIP_TRY(c, hipGetLastError());
     if (rec) {
         HIP_TRY(c, hipEventRecord(c->evs[2 * c->n_timed + 1], c->stream));
@@ -772,6 +793,7 @@ int dnaf_generate(dnaf_ctx* c, uint64_t row_begin, uint64_t n_rows, uint32_t wha
     p.row_begin = row_begin;
     p.n_rows = n_rows;
     p.rng_row0 = c->rng_row0;
+    p.rng_div = c->rng_div;
     p.key0 = (uint32_t)c->seed;
     p.key1 = (uint32_t)(c->seed >> 32);
     p.S = c->S; p.G = c->G; p.W = c->W;

@@ -86,7 +86,12 @@ struct MtGenParams {
     const uint32_t* states;   // [waves][624] block-aligned windows, wave w of this launch
     uint32_t start_off;       // offset of the first output word inside a wave's first block (0..623)
     uint32_t rows_per_wave;   // R
-    uint64_t wave0_row;       // table row (local to row_begin) of wave 0's first row may be negative? no: >= 0
+    uint64_t wave0_row;       // stream row (local to the call) of wave 0's first row
+    // stream row k of the call is drawn for table row row_phase + k * row_stride (local to row_begin): stride 1, phase 0
+    // ordinarily; with rng_div = N the call is launched N times, phase 0 .. N-1, over the same states -- the reference's
+    // N forked workers drawing the same stream for their stripes (pop_factory.py:426-434)
+    uint32_t row_stride, row_phase;
+    uint64_t n_stream_rows;   // stream rows of this launch
 };
 
 // SNPTuples.pick_allele_index on the 53-bit numerator: roll = r / 2^53, `cum >= roll` <=> r <= floor(cum * 2^53)
@@ -194,8 +199,8 @@ __global__ __launch_bounds__(64) void mt_rowgen_kernel(const MtGenParams mp)
     const uint32_t lane = threadIdx.x;
     const uint64_t wave = blockIdx.x;
     const uint64_t row_lo = mp.wave0_row + wave * mp.rows_per_wave; // local row index of this wave's first row
-    if (row_lo >= p.n_rows) return;
-    const uint64_t row_hi = min(p.n_rows, row_lo + mp.rows_per_wave);
+    if (row_lo >= mp.n_stream_rows) return;
+    const uint64_t row_hi = min(mp.n_stream_rows, row_lo + mp.rows_per_wave);
     const MtConsts K = mt_consts();
     uint32_t* ring = ring_store + ((4u - (mp.start_off & 3u)) & 3u);
 
@@ -207,7 +212,8 @@ __global__ __launch_bounds__(64) void mt_rowgen_kernel(const MtGenParams mp)
     const uint32_t S = p.S;
     const uint32_t row_words = 4u * S;
     const uint32_t row_pk_bytes = p.W * 4u;
-    for (uint64_t row_local = row_lo; row_local < row_hi; ++row_local) {
+    for (uint64_t stream_row = row_lo; stream_row < row_hi; ++stream_row) {
+        const uint64_t row_local = mp.row_phase + stream_row * mp.row_stride; // the table row these words are drawn for
         const RowRec rec = p.recs[p.row_begin + row_local];
         const uint64_t* thr = mp.thr53 + (p.row_begin + row_local) * 3u;
         const uint64_t T0 = mt_thr_key(thr[0]), T1 = mt_thr_key(thr[1]), T2 = mt_thr_key(thr[2]);

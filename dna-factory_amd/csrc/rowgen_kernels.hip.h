@@ -48,6 +48,7 @@ struct GenParams {
     uint64_t row_begin;        // first table row of this call
     uint64_t n_rows;
     uint64_t rng_row0;         // RNG row of table row 0
+    uint32_t rng_div;          // table rows k * rng_div .. k * rng_div + rng_div - 1 share RNG row k (1: every row its own)
     uint32_t key0, key1;       // Philox key = seed
     uint32_t S, G, W;          // samples, groups of 4, packed words per row
     uint32_t nseg, seg_groups; // segments per row, groups per segment (multiple of 64)
@@ -55,6 +56,11 @@ struct GenParams {
     uint32_t prefix_stride;    // rowmix_kernel: bytes per row in prefix_fixed (multiple of 16, <= 64); 0: no such copy
     const uint8_t* prefix_fixed; // [table rows][prefix_stride] the rows' fixed columns at a fixed stride
 };
+
+// RNG row (relative to rng_row0) of table row j.  rng_div > 1 reproduces the reference's forked workers, which all draw
+// the parent's stream: with -n N, rows k N + 1 .. k N + N of a work chunk are made from the same 2 S uniforms
+// (pop_factory.py:426-434).
+__device__ __forceinline__ uint64_t rng_row_of(const GenParams& p, uint64_t j) { return p.rng_div > 1u ? j / p.rng_div : j; }
 
 #define PHILOX_M0 0xD2511F53u
 #define PHILOX_M1 0xCD9E8D57u
@@ -534,7 +540,7 @@ __global__ __launch_bounds__(256) void rowgen_kernel(const GenParams p)
     const uint32_t g_end = min(p.G, g_begin + p.seg_groups);
     const uint32_t g_stop = (PACKED && g_end == p.G) ? p.W * 4u : g_end; // the last segment also zeroes the pad bytes
 
-    const uint64_t rng_row = p.rng_row0 + p.row_begin + row_local;
+    const uint64_t rng_row = p.rng_row0 + rng_row_of(p, p.row_begin + row_local);
     SegCtx c;
     c.t0 = rec.thr[0]; c.t1 = rec.thr[1]; c.t2 = rec.thr[2];
     c.r_lo = (uint32_t)rng_row; c.r_hi = (uint32_t)(rng_row >> 32);

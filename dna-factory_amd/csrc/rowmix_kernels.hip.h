@@ -131,7 +131,7 @@ __global__ DNAF_MIX_BOUNDS void rowmix_kernel(const GenParams p)
     const uint32_t my_rel = (uint32_t)(myrec.text_off - text0), my_plen = myrec.prefix_len, my_poff = myrec.prefix_off;
     {
         SegCtx cr;
-        const uint64_t rng_row = p.rng_row0 + p.row_begin + j0 + lane_id;
+        const uint64_t rng_row = p.rng_row0 + rng_row_of(p, p.row_begin + j0 + lane_id);
         cr.r_lo = (uint32_t)rng_row; cr.r_hi = (uint32_t)(rng_row >> 32);
         cr.k0 = p.key0; cr.k1 = p.key1;
         const RowConst rc = make_row_const(cr);

@@ -509,7 +509,7 @@ __device__ __forceinline__ void run_row_other(const SegCtx& c, uint32_t cls, uin
 
 __device__ __forceinline__ void make_ctx(SegCtx& c, const GenParams& p, const RowRec& rec, uint64_t row_local, uint8_t* row_text)
 {
-    const uint64_t rng_row = p.rng_row0 + p.row_begin + row_local;
+    const uint64_t rng_row = p.rng_row0 + rng_row_of(p, p.row_begin + row_local);
     c.t0 = rec.thr[0]; c.t1 = rec.thr[1]; c.t2 = rec.thr[2];
     c.r_lo = (uint32_t)rng_row; c.r_hi = (uint32_t)(rng_row >> 32);
     c.k0 = p.key0; c.k1 = p.key1;

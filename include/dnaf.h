@@ -114,6 +114,14 @@ int dnaf_set_mt_state(dnaf_ctx* ctx, const uint32_t* key, uint32_t pos, uint64_t
  * goes to device k mod G. */
 int dnaf_set_rng_row0(dnaf_ctx* ctx, uint64_t rng_row0);
 
+/* Table rows k*n .. k*n + n-1 share RNG row rng_row0 + k (n = 1, the default: every row its own).  This is what the
+ * reference's `-n n` does to the stream: its n forked workers all inherit the parent's numpy state and never reseed, so
+ * worker w draws for rows w+1, w+1+n, ... the very numbers worker 0 draws for rows 1, 1+n, ... (stripe_list
+ * common/snp.py:82-88, fork pop_factory.py:426-434).  Kept as a compatibility mode (--compat-workers) so that
+ * the reference's DEFAULT invocation (-n 2) can be reproduced seed for seed.  A range passed to dnaf_generate must start on
+ * a multiple of n. */
+int dnaf_set_rng_divisor(dnaf_ctx* ctx, uint32_t n);
+
 /* Upload the SNP table (the work_q argument, pop_factory.py:474) and lay out
  * the output: per-row integer thresholds, forced slot, text offsets. */
 int dnaf_set_snps(dnaf_ctx* ctx, const dnaf_snp_table* table);

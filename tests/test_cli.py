@@ -280,6 +280,8 @@ CONFIGS = {"config1": (100, 100, 100000), "config2": (1000, 1000, 1000000),
            # 2,000,001 SNPs: the reference cuts them into two work chunks and its forked workers restart the random stream at
            # each (pop_factory.py:402-411) -- what it writes for BASELINE configs 3 and 4 (5M / 40M SNPs)
            "chunks_2000001": (2, 2, 2000001)}
+# -n 2 / -n 3: the reference's forked workers draw one and the same stream, reproduced by --compat-workers
+WORKER_CONFIGS = {"workers2_100x20000": (50, 50, 20000, 2), "workers3_100x20001": (50, 50, 20001, 3)}
 EXTRA_FLAGS = {"chunks_2000001": ["--compat-chunk-restart"]}
 
 
@@ -390,6 +392,46 @@ def _assert_directory_equals(out, gold):
             assert not os.path.exists(os.path.join(out, name)), name
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("config", sorted(WORKER_CONFIGS))
+def test_default_worker_count_of_the_reference_is_reproduced(cli, tmp_path, config):
+    """`pop_factory.py -s 50 -c 50 -x 20000 -f 0.01 -n 2` -- the reference's DEFAULT worker count -- through the unmodified
+    reference (its two forked workers draw the same stream: rows 2k+1 and 2k+2 come from the same uniforms) against
+    `--rng mt19937 --compat-workers -n 2` here: the whole output directory, hash for hash.  Likewise -n 3 with a row
+    count that is not a multiple of three."""
+    gold = _config_golden(config)
+    n_ctrl, n_cases, n_snps, n_workers = WORKER_CONFIGS[config]
+    out = str(tmp_path / config)
+    p = _run_cli(["-s", str(n_cases), "-c", str(n_ctrl), "-x", str(n_snps), "-f", "0.01", "-n", str(n_workers), "--compat-workers",
+                  "--rng", "mt19937", "--seed", str(gold["numpy_seed"]), "--outdir", out, "--tile-rows", "7000"])
+    assert p.returncode == 0, p.stderr[-3000:]
+    _assert_directory_equals(out, gold)
+
+
+@pytest.mark.gpu
+def test_compat_workers_with_philox_matches_the_oracle_stripe_by_stripe(oracle, tmp_path):
+    """The same row -> stream-row map with the Philox stream (every kernel form takes rng_row = row // N): stripe w of the
+    output -- rows w, w + N, ... -- equals the oracle's lines for those rows drawn from stream rows 0, 1, ..."""
+    for S_half, n_snps, N in ((30, 1501, 3), (1100, 260, 2)):
+        out = tmp_path / ("w%d" % N)
+        r = _run_cli(["-s", str(S_half), "-c", str(S_half), "-x", str(n_snps), "-f", "0.01", "-n", str(N), "--compat-workers", "--seed", "99",
+                      "--outdir", str(out)])
+        assert r.returncode == 0, r.stderr[-3000:]
+        snps = []
+        for line in gzip.open(out / "snps.json.gz", "rt"):
+            o = json.loads(line)
+            snps.append((o["id"], o["chromosome"], o["position"], list(o["tuples"].items())))
+        _, samples = _expected_body_inputs(str(out))
+        rec = oracle.snp_records(snps)
+        sex, ctrl, off, ids = oracle.sample_arrays(samples)
+        body = gzip.open(out / "population.vcf.gz", "rb").read().split(b"#CHROM", 1)[1].split(b"\n", 1)[1]
+        lines = body.split(b"\n")[:-1]
+        assert len(lines) == n_snps
+        for w in range(N):
+            want, _, _ = oracle.generate(rec[w::N], sex, ctrl, off, ids, rng_mode=oracle.RNG_PHILOX, seed=99, rng_row0=0, want_packed=False)
+            assert b"".join(l + b"\n" for l in lines[w::N]) == want, (N, w)
+
+
 # ---- the reference README's multi-job workflow (README.md:69-103), three runs, against the unmodified reference ----
 def _workflow_commands(base, offset_step3=1000):
     d1, d2, d3 = (os.path.join(base, d) for d in ("step1", "step2", "step3"))
@@ -441,6 +483,18 @@ def test_readme_multi_job_workflow_equals_the_reference(cli, tmp_path):
                 assert fa[2] in carried[iid] and ca in ("1/1", "1"), (fa[2], iid, ca, cb)
                 n_forced += 1
     assert n_forced > 0
+
+
+@pytest.mark.gpu
+def test_readme_workflow_at_the_default_worker_count(cli, tmp_path):
+    """The README's three commands as written there -- no -n, i.e. the reference's default of two workers -- against
+    `--compat-workers` (tests/golden/workflow_n2_sha256.json)."""
+    gold = _config_golden("workflow_n2")
+    common = ["--compat-workers", "--rng", "mt19937", "--seed", str(gold["step1"]["numpy_seed"]), "--compat-deleterious-file-bug"]
+    for step, out, args in _workflow_commands(str(tmp_path)):
+        p = _run_cli(args + common + ["--outdir", out])
+        assert p.returncode == 0, p.stderr[-3000:]
+        _assert_directory_equals(out, gold[step])
 
 
 def test_workflow_sample_files_equal_the_reference(cli, tmp_path):
