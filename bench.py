@@ -334,7 +334,7 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "frac_of_measured_copy_6290_GBs": achieved / 6290.0, "traffic": traffic,
                          "traffic_source": traffic_source,
                          "bytes_per_launch": bytes_per_launch, "kernel_ms_mean": mean_kernel_s * 1e3,
-                         "launches_timed": n_rec, "kernel": ("rowrun_kernel" if S > 2032 else "rowmix_kernel") if a.rng == "philox" else "mt_rowgen_kernel (+ mt_jump_kernel)",
+                         "launches_timed": n_rec, "kernel": gen.ctx.last_kernel() + (" (+ mt_jump_kernel)" if a.rng == "mt19937" else ""),
                          "draws_per_s": 2.0 * S * a.tile_rows / mean_kernel_s},
         }
         if a.bgzf_tiles > 0 and (what & capi.OUT_TEXT):
@@ -355,6 +355,9 @@ def main():
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
+    for rk in (ranks if (env_world == 1 and n > 1) else [r]):  # contexts are closed, not left to the interpreter's exit
+        if rk is not None:
+            rk.gen.close()
     if env_world > 1:
         import torch.distributed as dist
 

@@ -33,7 +33,7 @@ SYMBOLS = [
     "dnaf_reserve_output",
     "dnaf_sync", "dnaf_last_generate_ms", "dnaf_timing_begin", "dnaf_timing_end", "dnaf_read_text", "dnaf_read_packed", "dnaf_device_buffers",
     "dnaf_format_prefixes", "dnaf_bgzf_compress", "dnaf_read_bgzf", "dnaf_last_bgzf_ms",
-    "dnaf_bgzf_tables_from_histogram", "dnaf_gtz_tables_from_histogram", "dnaf_set_mt_state", "dnaf_set_rng_row0", "dnaf_set_rng_divisor", "dnaf_mt_jump_host", "dnaf_mt_characteristic_polynomial",
+    "dnaf_bgzf_tables_from_histogram", "dnaf_gtz_tables_from_histogram", "dnaf_set_mt_state", "dnaf_set_rng_row0", "dnaf_set_rng_divisor", "dnaf_last_kernel", "dnaf_mt_jump_host", "dnaf_mt_characteristic_polynomial",
     "dnaf_fetch_bgzf", "dnaf_fetch_text", "dnaf_read_text_range", "dnaf_format_snps_json", "dnaf_parse_snps_json",
     "dnaf_allele_counts", "dnaf_export_bed", "dnaf_read_bed", "dnaf_packed_pitch_words", "dnaf_numpy_legacy_choice",
 ]
@@ -107,6 +107,7 @@ def _load():
         "dnaf_set_mt_state": (ci, [vp, vp, u32, u64]),
         "dnaf_set_rng_row0": (ci, [vp, u64]),
         "dnaf_set_rng_divisor": (ci, [vp, u32]),
+        "dnaf_last_kernel": (ci, [vp, vp, u64]),
         "dnaf_fetch_bgzf": (ci, [vp, vp, vp]),
         "dnaf_fetch_text": (ci, [vp, vp, vp]),
         "dnaf_read_text_range": (ci, [vp, u64, u64, vp]),
@@ -147,7 +148,10 @@ def numpy_legacy_choice(pop_size, size):
     import numpy
 
     st = numpy.random.get_state()
-    if st[0] != "MT19937" or size > pop_size or pop_size >= 2**32 or pop_size == 0:
+    # the replay traces each wanted entry back through the shuffle's swaps: O(pop_size x size) compares -- right for the
+    # handful of weights a deleterious group has, not for hundreds (a group with 200 weights over 40 M SNPs: numpy's own
+    # shuffle, 2 s, is the faster one from about 32 entries up)
+    if st[0] != "MT19937" or size > pop_size or pop_size >= 2**32 or pop_size == 0 or size > 32:
         return numpy.random.choice(pop_size, size, replace=False)
     key = np.ascontiguousarray(st[1], dtype=np.uint32).copy()
     pos = ctypes.c_uint32(int(st[2]))
@@ -295,6 +299,12 @@ class Context:
     def set_rng_row0(self, rng_row0):
         """Only the RNG row of table row 0 changes (the next tile of a larger job); mode, seed and cached state stay."""
         self._check(lib.dnaf_set_rng_row0(self._h, int(rng_row0)))
+
+    def last_kernel(self):
+        """Name of the row kernel the last generate() launched."""
+        buf = ctypes.create_string_buffer(64)
+        self._check(lib.dnaf_last_kernel(self._h, buf, 64))
+        return buf.value.decode()
 
     def set_rng_divisor(self, n):
         """Table rows k n .. k n + n - 1 share RNG row k: the stream of the reference's `-n n` forked workers."""

@@ -53,4 +53,14 @@ __global__ __launch_bounds__(256) void bed_kernel(const uint32_t* packed, const 
         for (uint32_t k = 0; k < nbytes; ++k) dst[k] = (uint8_t)(out >> (8u * k));
 }
 
+// packed rows Wp words apart -> dense rows of W words (dnaf_read_packed)
+__global__ __launch_bounds__(256) void packed_compact_kernel(const uint32_t* src, uint32_t* dst, uint64_t n_rows, uint32_t W, uint32_t Wp)
+{
+    const uint64_t total = n_rows * W;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x; i < total; i += (uint64_t)gridDim.x * 256u) {
+        const uint64_t r = i / W;
+        dst[i] = src[r * Wp + (i - r * W)];
+    }
+}
+
 } // namespace dnaf

@@ -142,6 +142,10 @@ int dnaf_generate(dnaf_ctx* ctx, uint64_t row_begin, uint64_t n_rows, uint32_t w
  * padding of its device pitch itself). */
 int dnaf_reserve_output(dnaf_ctx* ctx, uint64_t text_bytes, uint64_t packed_words);
 int dnaf_sync(dnaf_ctx* ctx);
+/* Name of the row kernel the last dnaf_generate launched ("rowrun_kernel", "rowmix_kernel", "rowgen_kernel",
+ * "mt_rowgen_kernel"; "" before the first call): which form of the worker loop (pop_factory.py:471-513) a measurement
+ * is a measurement of. */
+int dnaf_last_kernel(dnaf_ctx* ctx, char* name, uint64_t cap);
 
 /* Device time (HIP events on the context's stream) of the last
  * dnaf_generate, in milliseconds.  Synchronises. */

@@ -174,7 +174,8 @@ def test_numpy_legacy_choice_replay_is_numpy():
 
     rs = np.random.RandomState(5)
     cases = [(1, 1), (2, 1), (2, 2), (3, 2), (10, 3), (7, 7), (623, 2), (624, 5), (625, 3), (1000, 10), (65535, 4), (65536, 5), (65537, 4),
-             (1000003, 10)] + [(int(rs.randint(1, 300000)), int(rs.randint(1, 12))) for _ in range(20)]
+             (1000003, 10), (5000, 32), (5000, 33), (40000, 200)]  # 32 entries: the last the C replay takes; beyond, numpy's own shuffle
+    cases += [(int(rs.randint(1, 300000)), int(rs.randint(1, 12))) for _ in range(20)]
     for n, k in cases:
         k = min(k, n)
         for pre in (0, 1, 623, 624, 625, int(rs.randint(0, 3000))):
