@@ -466,6 +466,47 @@ __device__ __forceinline__ bool run_row_biallelic(const SegCtx& c, uint32_t skip
     return head_done;
 }
 
+// One complete group of a biallelic X row from its packed byte (the hand-written Philox group gives all eight alleles; a
+// male's second allele is drawn and dropped, pop_factory.py:477, :486-494): the diploid text of the four cells comes from
+// the LDS table, the males' cells are cut to "a\t" and the cells shifted together in registers (as x_fast does from its own
+// draws); the lane stores the first 8 and the last 8 bytes of its 8..16-byte run.
+template <bool TEXT, bool PACKED>
+__device__ __forceinline__ void x_group_from_code(const SegCtx& c, uint32_t g, uint32_t pk)
+{
+    const uint32_t m = c.male_nib[g];
+    if (TEXT) {
+        const u32x4_t w = c.lut[pk & 0xFFu];
+        const bool m0 = m & 1u, m1 = m & 2u, m2 = m & 4u, m3 = m & 8u;
+        const uint32_t c0 = m0 ? (w.x & 0xFFu) | 0x0900u : w.x, c1 = m1 ? (w.y & 0xFFu) | 0x0900u : w.y;
+        const uint32_t c2 = m2 ? (w.z & 0xFFu) | 0x0900u : w.z, c3 = m3 ? (w.w & 0xFFu) | 0x0900u : w.w;
+        uint32_t r0 = c3, r1, r2, r3;
+        r1 = m2 ? r0 >> 16 : r0;
+        r0 = m2 ? (r0 << 16) | c2 : c2;
+        r2 = m1 ? r1 >> 16 : r1;
+        r1 = m1 ? __builtin_amdgcn_alignbit(r1, r0, 16) : r0;
+        r0 = m1 ? (r0 << 16) | c1 : c1;
+        r3 = m0 ? r2 >> 16 : r2;
+        r2 = m0 ? __builtin_amdgcn_alignbit(r2, r1, 16) : r1;
+        r1 = m0 ? __builtin_amdgcn_alignbit(r1, r0, 16) : r0;
+        r0 = m0 ? (r0 << 16) | c0 : c0;
+        const uint32_t sl = 8u - 2u * (uint32_t)__builtin_popcount(m); // run length - 8, in bytes
+        const uint32_t q = sl >> 2, sh = (sl & 2u) << 3;
+        const uint32_t t0 = q == 0u ? r0 : (q == 1u ? r1 : r2);
+        const uint32_t t1 = q == 0u ? r1 : (q == 1u ? r2 : r3);
+        const uint32_t t2 = q == 0u ? r2 : (q == 1u ? r3 : 0u);
+        uint8_t* dst = c.cells + c.xoff[g];
+        const uint2 head = make_uint2(r0, r1);
+        const uint2 tail = make_uint2(__builtin_amdgcn_alignbit(t1, t0, sh), __builtin_amdgcn_alignbit(t2, t1, sh));
+        store_unaligned<8>(dst, &head);
+        store_unaligned<8>(dst + sl, &tail);
+    }
+    if (PACKED) {
+        uint32_t sp = (m | (m << 2)) & 0x33u; // male bit k -> bit 2k
+        sp = (sp | (sp << 1)) & 0x55u;
+        c.prow[g] = (uint8_t)(pk & ~(sp << 1)); // haploid: no second allele
+    }
+}
+
 // Number of leading groups of a row whose cells begin below cell-stream offset `bytes` (<= 127): those are the
 // groups a line boundary `bytes` into the cell stream can cut.  At most 16 (a group is at least 8 bytes).
 __device__ __forceinline__ uint32_t groups_below(const SegCtx& c, uint32_t cls, uint32_t bytes, uint32_t lane)
@@ -492,8 +533,19 @@ __device__ __forceinline__ void run_row_other(const SegCtx& c, uint32_t cls, uin
         for (; gb < g_fast; gb += 64u)
             if (gb + lane < g_fast) autosome_fast<TEXT, PACKED, MULTI>(c, gb + lane);
     } else if (cls == 1u && !MULTI) {
-        for (; gb < g_fast; gb += 64u)
-            if (gb + lane < g_fast) x_fast<TEXT, PACKED>(c, gb + lane);
+        // X rows are one row in twenty: the same hand-written Philox group as the autosome rows (90 instructions instead of
+        // the compiler's 110 + the compares), its packed byte turned into text through the LDS table
+        const RowConst rc = make_row_const(c);
+        const RowKeys keys = make_row_keys(c.k0, c.k1);
+        const uint64_t pl = (uint64_t)PHILOX_M0 * (2u * lane);
+        for (; gb < g_fast; gb += 64u) {
+            const uint64_t off = (uint64_t)PHILOX_M0 * (2u * gb);
+            uint32_t pk = group_code(pl, off, off + PHILOX_M0, rc, keys, c.t0);
+            if (gb + lane < g_fast) {
+                if (c.frow) pk = force_code(c, pk, gb + lane);
+                x_group_from_code<TEXT, PACKED>(c, gb + lane, pk);
+            }
+        }
     } else if (cls == 2u) {
         for (; gb < g_fast; gb += 64u)
             if (gb + lane < g_fast) haploid_fast<TEXT, PACKED, MULTI, true>(c, gb + lane);

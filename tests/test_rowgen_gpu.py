@@ -319,6 +319,26 @@ def test_line_owning_kernel_fuzz(RowGenerator, oracle, monkeypatch, rpw):
         check_case(RowGenerator, oracle, snps, samples, seed=int(rs.randint(0, 2**31)), rng_row0=int(rs.randint(0, 1000)))
 
 
+@pytest.mark.parametrize("rpw", [1, 3, 64])
+def test_line_owning_kernel_on_dense_rows(RowGenerator, oracle, monkeypatch, rpw):
+    """rowrun_kernel's dense (unpadded-pitch) path: packed rows shorter than 128 words (1,021 .. 2,032 samples) normally go
+    to the short-row kernel, so this path -- whole rows per wave, head / skip line ownership over a dense packed matrix --
+    only runs with DNAF_NO_ROWMIX (the library's switch for A/B runs); it ships, so it is tested."""
+    monkeypatch.setenv("DNAF_NO_ROWMIX", "1")
+    monkeypatch.setenv("DNAF_MIN_RUN_WAVES", "0")
+    monkeypatch.setenv("DNAF_ROWS_PER_WAVE", str(rpw))
+    rs = np.random.RandomState(31 + rpw)
+    for case in range(10):
+        S = int(rs.randint(1021, 2033))
+        snps, samples = random_case(rs, int(rs.randint(1, 70)), S, p_sex_chrom=0.4)
+        with RowGenerator(device=0, seed=1) as probe:  # the switch took: this shape would otherwise run rowmix_kernel
+            probe.set_samples(samples)
+            probe.set_snps(snps)
+            probe.ctx.generate(0, len(snps), 3)
+            assert probe.ctx.last_kernel() == "rowrun_kernel"
+        check_case(RowGenerator, oracle, snps, samples, seed=int(rs.randint(0, 2**31)), rng_row0=int(rs.randint(0, 1000)))
+
+
 @pytest.mark.parametrize("rpw", [1, 5, 64])
 def test_short_row_kernel_fuzz(RowGenerator, oracle, monkeypatch, rpw):
     """The short-row form (rowmix_kernels.hip.h: the lanes of a trip span the rows of a wave's run) at 1 .. 64 rows per

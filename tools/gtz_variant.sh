@@ -1,5 +1,5 @@
 #!/bin/bash
-# build_ab/libdnaf_gtz_NAME.so = the library compiled with extra flags (encoder experiments; tools/gtz_ab.sh runs them)
+# build_ab/libdnaf_gtz_NAME.so = the library compiled with extra flags (encoder experiments; tools/measure.sh gtz-ab runs them)
 set -e
 n=$1; shift
 cd "$(dirname "$0")/../dna-factory_amd/csrc"
