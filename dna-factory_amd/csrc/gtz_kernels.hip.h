@@ -521,14 +521,24 @@ __global__ __launch_bounds__(THREADS) GTZ_OCCUPANCY void gtz_encode(const GtzPar
             const uint32_t c64 = (kb >> 6) + local - 1u;
             const uint32_t k0 = max(kb, 64u * c64), k1 = min(ke, 64u * c64 + 64u);
             ch = gtz_load_chunk(s, i, c64, k0, k1);
-            evs = gtz_find_matches(s, i, c64, ch, DNAF_GTZ_EXP != 1);
+            evs = gtz_find_matches<!HIST>(s, i, c64, ch, DNAF_GTZ_EXP != 1);
             if (HIST) {
                 GtzSymbolCount hs{s->hist()};
                 gtz_walk(ch, evs, hs);
             } else {
-                GtzBitCount cnt{s->gap(), s->len4(), s->dist(), lit_bits, 0};
-                if (DNAF_GTZ_EXP != 3) gtz_walk(ch, evs, cnt);
-                bits = DNAF_GTZ_EXP == 3 ? 150u : cnt.bits;
+                bits = DNAF_GTZ_EXP == 3 ? 150u : gtz_count_bits(ch, evs, s->gap(), lit_bits);
+#ifdef DNAF_GTZ_CHECK_COUNT
+                { // debug builds: the mask arithmetic against the walk it replaces
+                    GtzBitCount cnt{s->gap(), s->len4(), s->dist(), lit_bits, 0};
+                    gtz_walk(ch, evs, cnt);
+                    if (cnt.bits != bits) {
+                        printf("gtz count mismatch: member %u item %u: %u (masks) vs %u (walk) j0 %u j1 %u head %d ev %016llx:%016llx far %016llx:%016llx\n", m, tid, bits,
+                               cnt.bits, ch.j0, ch.j1, (int)ch.head, (unsigned long long)evs.ev.hi, (unsigned long long)evs.ev.lo, (unsigned long long)evs.far.hi,
+                               (unsigned long long)evs.far.lo);
+                        bits = cnt.bits;
+                    }
+                }
+#endif
                 // CRC of the chunk's bytes from its cells: base pattern + one unit per '1' allele.  Only the set bits of the
                 // chunk's code words are visited (a tenth to a third of the 128 alleles), not every cell.
                 const uint32_t n = k1 - k0;

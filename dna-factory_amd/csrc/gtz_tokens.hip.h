@@ -67,15 +67,18 @@ struct GtzEvents {
     GtzMask far;  // subset: first allele of each far match
     GtzMask ends; // bit 2 e for every cell e < 64 at which a far match ends
     GtzFarQueue dist;
+    uint32_t far_bits; // deflate bits of the far matches' own symbols (length code + extra, distance code + extra), summed
 };
 
 
 // LZ77 matches of one chunk (see gtz_kernels.hip.h) and the chunk's event masks.  Lanes step from break to break
 // together; a break is only looked up when the 16 cells from it hold at least GTZ_MIN_BREAKS differing alleles.
+template <bool COUNT>
 __device__ __forceinline__ GtzEvents gtz_find_matches(GtzShared* s, uint32_t i, uint32_t c64, const GtzChunk& c, bool search)
 {
     GtzEvents E;
     E.dist.clear();
+    E.far_bits = 0;
     const GtzMask valid = gtz_range(2u * c.j0, 2u * c.j1);
     E.ev.lo = c.xlo & valid.lo;
     E.ev.hi = c.xhi & valid.hi;
@@ -85,27 +88,33 @@ __device__ __forceinline__ GtzEvents gtz_find_matches(GtzShared* s, uint32_t i, 
     if (search && c.j1 >= GTZ_KEY_CELLS + c.j0) {
         const uint32_t gbase = 16u * s->gw[i] - 16u * s->kw0[i] + 64u * c64; // g of the chunk's cell 0
         const int32_t delta_i = s->row[i].delta;
-        const uint64_t blo = (c.xlo | (c.xlo >> 1)) & 0x5555555555555555ull;
-        const uint64_t bhi = (c.xhi | (c.xhi >> 1)) & 0x5555555555555555ull;
-        const uint32_t last = c.j1 - GTZ_KEY_CELLS; // last cell a match can start at
-        uint32_t pos = c.j0;
-        for (;;) {
-            const uint32_t j = gtz_next_break(blo, bhi, pos);
-            if (j > last || nfar >= GTZ_MAX_FAR) break;
-            // alleles that differ from the cell before, in the 16 cells from j
-            const uint32_t xw = j < 32u ? (uint32_t)((c.xlo >> (2u * j)) | (j ? c.xhi << (64u - 2u * j) : 0ull)) : (uint32_t)(c.xhi >> (2u * j - 64u));
-            if ((uint32_t)__builtin_popcount(xw) < GTZ_MIN_BREAKS) { pos = j + 1u; continue; }
+        // Cells that differ from their predecessor and can begin a match (one bit per cell, at its allele a), consumed from
+        // the bottom.  The chunk's own cells are read back from LDS as 16-cell windows (one ds_read2 + one alignbit) rather
+        // than shifted out of the registers (a 128-bit funnel shift by a variable: 15 instructions).
+        const GtzMask startable = gtz_range(2u * c.j0, 2u * (c.j1 - GTZ_KEY_CELLS + 1u));
+        uint64_t rlo = (c.xlo | (c.xlo >> 1)) & 0x5555555555555555ull & startable.lo;
+        uint64_t rhi = (c.xhi | (c.xhi >> 1)) & 0x5555555555555555ull & startable.hi;
+        while ((rlo | rhi) && nfar < GTZ_MAX_FAR) {
+            const bool low = rlo != 0;
+            const uint64_t rr = low ? rlo : rhi;
+            const uint64_t bit = rr & (0ull - rr); // the cell's allele-a bit within its half
+            const uint32_t j = (low ? 0u : 32u) + ((uint32_t)__builtin_ctzll(rr) >> 1);
+            if (low) rlo ^= bit; else rhi ^= bit;
             const uint32_t g = gbase + j;
-            const uint32_t dw = c.window(j);
+            const uint32_t dw = gtz_window(s->cells, g);
+            // alleles that differ from the cell before, in the 16 cells from j
+            uint32_t xw = dw ^ (g ? gtz_window(s->cells, g - 1u) : dw << 2);
+            if (c.head && j == c.j0) xw |= 3u; // nothing before a row's first cell in the member
+            if ((uint32_t)__builtin_popcount(xw) < GTZ_MIN_BREAKS) continue;
             const uint32_t key = dw & (GTZ_KEYS - 1u);
             const uint32_t q = gtz_segment(g);
-            // candidates: earliest in this quarter, latest / earliest in the one before, latest two back
+            // candidates: earliest in this segment, latest / earliest in the one before, latest two back
             uint32_t cand[GTZ_CANDS];
             cand[0] = s->tab16[(2u * q) * GTZ_KEYS + key]; // 0xFFFF (none) is never below g
             cand[1] = q ? (uint32_t)s->tab16[(2u * (q - 1u) + 1u) * GTZ_KEYS + key] - 1u : 0xFFFFFFFFu;
 #if DNAF_GTZ_CANDS > 2
             cand[2] = q ? (uint32_t)s->tab16[(2u * (q - 1u)) * GTZ_KEYS + key] : 0xFFFFFFFFu;
-            if (cand[2] == cand[1]) cand[2] = 0xFFFFFFFFu; // one occurrence in that quarter: same position twice
+            if (cand[2] == cand[1]) cand[2] = 0xFFFFFFFFu; // one occurrence in that segment: same position twice
 #endif
 #if DNAF_GTZ_CANDS > 3
             cand[3] = q > 1u ? (uint32_t)s->tab16[(2u * (q - 2u) + 1u) * GTZ_KEYS + key] - 1u : 0xFFFFFFFFu;
@@ -131,24 +140,31 @@ __device__ __forceinline__ GtzEvents gtz_find_matches(GtzShared* s, uint32_t i, 
             // longer than one window: keep comparing (rare except in sparse rows); only the candidate chosen on the first 16 cells
             if (f == 16u)
                 while (f < flim) {
-                    const uint32_t x = c.window(j + f) ^ gtz_window(s->cells, fsrc + f);
+                    const uint32_t x = gtz_window(s->cells, g + f) ^ gtz_window(s->cells, fsrc + f);
                     if (x) { f = min(flim, f + ((uint32_t)__builtin_ctz(x) >> 1)); break; }
                     f = min(flim, f + 16u);
                 }
-            bool take = f >= GTZ_KEY_CELLS;
-            if (take) {
-                const GtzMask m = gtz_range(2u * j, 2u * (j + f));
-                take = (uint32_t)(__builtin_popcountll(c.xlo & m.lo) + __builtin_popcountll(c.xhi & m.hi)) >= GTZ_MIN_BREAKS;
-                if (take) {
-                    E.dist.push(nfar++, dbytes);
-                    E.ev.lo &= ~m.lo;
-                    E.ev.hi &= ~m.hi;
-                    if (j < 32u) E.far.lo |= 1ull << (2u * j); else E.far.hi |= 1ull << (2u * j - 64u);
-                    const uint32_t e = j + f;
-                    if (e < 32u) ends_lo |= 1ull << (2u * e); else if (e < 64u) ends_hi |= 1ull << (2u * e - 64u);
-                }
+            // worth a match: five cells or more that hold three differing alleles or more (16 cells from j hold that many)
+            if (f < GTZ_KEY_CELLS || (f < 16u && (uint32_t)__builtin_popcount(xw & ((1u << (2u * f)) - 1u)) < GTZ_MIN_BREAKS)) continue;
+            E.dist.push(nfar++, dbytes);
+            if (COUNT) { // what the match will cost, while f and the distance are at hand (the bit count needs no walk over them)
+                uint32_t sym, eb, ev;
+                gtz_dist_symbol(dbytes, &sym, &eb, &ev);
+                E.far_bits += (s->len4()[f] & 31u) + (s->dist()[sym] & 31u) + eb;
             }
-            pos = take ? j + f : j + 1u;
+            // alleles [2 j, 2 (j + f)) leave the events and the cells that can begin a match; masks below 2 j from the cell's own
+            // bit, below 2 (j + f) by one shift
+            const uint64_t below_lo = low ? bit - 1ull : ~0ull, below_hi = low ? 0ull : bit - 1ull;
+            const uint32_t e2 = 2u * (j + f);
+            const uint64_t upto_lo = gtz_low_mask(min(e2, 64u)), upto_hi = gtz_low_mask(e2 > 64u ? e2 - 64u : 0u);
+            E.ev.lo &= ~(upto_lo & ~below_lo);
+            E.ev.hi &= ~(upto_hi & ~below_hi);
+            rlo &= ~upto_lo;
+            rhi &= ~upto_hi;
+            if (low) E.far.lo |= bit; else E.far.hi |= bit;
+            // the end mark is the bit just above `upto` (none when the match ends with the chunk's 64th cell)
+            ends_lo |= upto_lo + 1ull; // (all ones + 1 = 0)
+            if (upto_lo == ~0ull) ends_hi |= upto_hi + 1ull;
         }
     }
     // forced literals: allele a at the start of a run that allele b of the same cell cuts to two bytes
@@ -250,6 +266,90 @@ struct GtzBitEmit {
         put((de >> 5) | (ev << dn), dn + eb); // <= 15 + 13 bits
     }
 };
+
+// first set bit of a 128-bit mask at or above position `from` (128: none)
+__device__ __forceinline__ uint32_t gtz_next_bit(uint64_t lo, uint64_t hi, uint32_t from)
+{
+    if (from < 64u) {
+        const uint64_t t = lo & ~gtz_low_mask(from);
+        if (t) return (uint32_t)__builtin_ctzll(t);
+        return hi ? 64u + (uint32_t)__builtin_ctzll(hi) : 128u;
+    }
+    if (from >= 128u) return 128u;
+    const uint64_t t = hi & ~gtz_low_mask(from - 64u);
+    return t ? 64u + (uint32_t)__builtin_ctzll(t) : 128u;
+}
+
+// Deflate bits of a chunk's tokens WITHOUT walking its events (what gtz_walk with a counting sink returns, and must: the
+// chunks' bit offsets in the member come from it).  Every event is followed by a gap that ends at the next event, so the
+// gaps are counted by how far the next event is: breaking alleles with an event right behind them (one byte between:
+// the separator's literal) or two alleles on (three bytes: the shortest match) are counted with shifted masks and
+// popcounts -- in dense rows that is nearly all of them; only the alleles with a longer gap behind them, the ends of the
+// far matches and the start of the chunk take a table read each.  The far matches' own symbols were priced by the search.
+__device__ __forceinline__ uint32_t gtz_count_bits(const GtzChunk& c, const GtzEvents& E, const uint32_t* gap, uint32_t lit_n)
+{
+    GtzMask ev = E.ev;
+    uint32_t bits = E.far_bits;
+    uint32_t s0 = c.j0; // the cell at whose boundary the first gap begins
+    if (c.head && !((c.j0 < 32u ? E.far.lo >> (2u * c.j0) : E.far.hi >> (2u * c.j0 - 64u)) & 1ull)) {
+        const uint32_t code = c.code(c.j0);
+        bits += ((lit_n >> (8u * (code & 1u))) & 0xFFu) + ((lit_n >> (8u * (code >> 1))) & 0xFFu) + ((lit_n >> 16) & 0xFFu) + (lit_n >> 24);
+        const GtzMask m = gtz_range(2u * c.j0, 2u * c.j0 + 2u);
+        ev.lo &= ~m.lo;
+        ev.hi &= ~m.hi;
+        s0 = c.j0 + 1u;
+    }
+    // events plus the chunk's end as a pseudo-event (allele 2 j1; past the mask when the chunk has all 64 cells)
+    uint64_t xlo = ev.lo, xhi = ev.hi;
+    if (c.j1 < 32u) xlo |= 1ull << (2u * c.j1); else if (c.j1 < 64u) xhi |= 1ull << (2u * c.j1 - 64u);
+    const uint32_t end2 = 2u * c.j1; // where a gap ends when no event follows
+    const uint64_t blo = ev.lo & ~E.far.lo, bhi = ev.hi & ~E.far.hi; // literal events: breaking alleles and forced ones
+    // their own literals
+    const uint32_t n1 = (uint32_t)(__builtin_popcountll(blo & c.lo) + __builtin_popcountll(bhi & c.hi));
+    const uint32_t n0 = (uint32_t)(__builtin_popcountll(blo) + __builtin_popcountll(bhi)) - n1;
+    bits += n0 * (lit_n & 0xFFu) + n1 * ((lit_n >> 8) & 0xFFu);
+    // the next event one allele on: one byte between, '/' behind an allele a (even index), tab behind an allele b
+    const uint64_t s1lo = (xlo >> 1) | (xhi << 63), s1hi = xhi >> 1;
+    const uint64_t s2lo = (xlo >> 2) | (xhi << 62), s2hi = xhi >> 2;
+    const uint64_t a1lo = blo & s1lo, a1hi = bhi & s1hi;
+    const uint32_t n_slash = (uint32_t)(__builtin_popcountll(a1lo & 0x5555555555555555ull) + __builtin_popcountll(a1hi & 0x5555555555555555ull));
+    const uint32_t n_tab = (uint32_t)(__builtin_popcountll(a1lo) + __builtin_popcountll(a1hi)) - n_slash;
+    bits += n_slash * ((lit_n >> 16) & 0xFFu) + n_tab * (lit_n >> 24);
+    // two alleles on: three bytes between
+    const uint64_t a2lo = blo & ~s1lo & s2lo, a2hi = bhi & ~s1hi & s2hi;
+    bits += (uint32_t)(__builtin_popcountll(a2lo) + __builtin_popcountll(a2hi)) * (gap[3] & 31u);
+    // the rest of the literal events: a longer gap (or the chunk's end) behind them
+    {
+        uint64_t rlo = blo & ~s1lo & ~s2lo, rhi = bhi & ~s1hi & ~s2hi;
+        while (rlo | rhi) {
+            const bool low = rlo != 0;
+            const uint32_t p = low ? (uint32_t)__builtin_ctzll(rlo) : 64u + (uint32_t)__builtin_ctzll(rhi);
+            if (low) rlo &= rlo - 1ull; else rhi &= rhi - 1ull;
+            const uint32_t nx = gtz_next_bit(xlo, xhi, p + 1u);
+            const uint32_t L = 2u * ((nx < 128u ? nx : end2) - p) - 1u;
+            // L >= 5 (the same entry in both halves of the table) -- except behind the last alleles of a chunk that has all
+            // 64 cells, whose end is no bit of the mask: three bytes, or one, the tab behind allele b of the last cell
+            bits += gap[L + (p & 1u) * GTZ_GAP_STRIDE] & 31u;
+        }
+    }
+    // the gaps behind the far matches (they begin on a cell boundary: an even number of bytes, never two)
+    {
+        uint64_t zlo = E.ends.lo, zhi = E.ends.hi;
+        while (zlo | zhi) {
+            const bool low = zlo != 0;
+            const uint32_t z = low ? (uint32_t)__builtin_ctzll(zlo) : 64u + (uint32_t)__builtin_ctzll(zhi);
+            if (low) zlo &= zlo - 1ull; else zhi &= zhi - 1ull;
+            const uint32_t nx = gtz_next_bit(xlo, xhi, z);
+            bits += gap[2u * ((nx < 128u ? nx : end2) - z)] & 31u;
+        }
+    }
+    // and the gap at the chunk's start
+    {
+        const uint32_t nx = gtz_next_bit(xlo, xhi, 2u * s0);
+        bits += gap[2u * ((nx < 128u ? nx : end2) - 2u * s0)] & 31u;
+    }
+    return bits;
+}
 
 // Visit the chunk's events in byte order.
 template <class Sink>
