@@ -24,7 +24,7 @@ constexpr uint32_t GTZ_NSYM = 320;      // histogram layout per class: [0,286) l
 constexpr uint32_t GTZ_DIST0 = 286;
 constexpr uint32_t GTZ_HDR_WORDS = 64;  // header bits of a class (<= 2048)
 constexpr uint32_t GTZ_CHUNK_CELLS = 64; // cells (= 256 text bytes) tokenised by one thread
-constexpr uint32_t GTZ_GAP_STRIDE = 264; // entries per half of the gap table (gap lengths 0..256)
+constexpr uint32_t GTZ_GAP_STRIDE = 264; // entries of the gap table (gap lengths 0..256)
 
 // Entries are (bit pattern << 5) | bit count, patterns in LSB-first stream order.
 struct GtzClassTables {
@@ -36,10 +36,10 @@ struct GtzClassTables {
     uint32_t hdr[GTZ_HDR_WORDS];
     uint64_t len_nb[2];  // code length of length symbol 257 + n at nibble n (the bit-count pass works from registers)
     uint64_t dist_nb[2]; // code length of distance symbol n at nibble n
-    // gap[h][L]: the L bytes between two events of a chunk (gtz_tokens.hip.h), every one repeating the byte four back:
-    // L >= 3 one match (length code + extra bits + the code of distance 4), L = 1 the separator's literal -- '/' in
-    // half 0 (the gap begins behind allele a), '\t' in half 1 (behind allele b) --, L = 0 nothing.  At most 27 bits.
-    uint32_t gap[2 * GTZ_GAP_STRIDE];
+    // gap[L]: the L bytes between two events of a chunk (gtz_tokens.hip.h), every one repeating the byte four back:
+    // L >= 3 one match (length code + extra bits + the code of distance 4), L = 0 nothing; L = 1 is the separator's
+    // literal, '/' behind an allele a (this table) or the tab behind an allele b (the kernel takes lit['\t']).  At most 27 bits.
+    uint32_t gap[GTZ_GAP_STRIDE];
     uint32_t len4[GTZ_CHUNK_CELLS + 8]; // LZ77 match of f cells (4 f bytes) -> length code + extra bits
     uint32_t unit_ok;    // 1: a gap code and the literal '0' / '1' behind it fit 32 bits together (what the kernel emits as one unit)
 };
@@ -52,6 +52,9 @@ struct GtzTables {
     uint32_t crc_unit_b[GTZ_CHUNK_CELLS];    // ... the second allele
     uint32_t crc_shift_chunk[1024];          // x^(8*64*j) mod P
     uint32_t crc_shift_byte[256];            // x^(8*r) mod P
+    // the two unit tables folded by pairs of cells: crc_nib[P][v] = change of a chunk's CRC when the four alleles of the
+    // cells 2 P + 1 and 2 P before its end are v (bit 0 / 1: alleles a / b of the earlier cell, bit 2 / 3: of the later one)
+    uint32_t crc_nib[(GTZ_CHUNK_CELLS / 2) * 16];
 };
 
 inline uint32_t crc32_bytes(const uint32_t* table, const uint8_t* p, size_t n)
@@ -113,10 +116,9 @@ inline void gtz_build_class(const uint64_t* litlen_hist, const uint64_t* dist_hi
         const uint32_t n = ln + dn;
         widest = n > widest ? n : widest;
         const uint32_t e = n <= 27 ? (((le >> 5) | (dc[3] << ln)) << 5) | n : 0u;
-        t->gap[L] = t->gap[GTZ_GAP_STRIDE + L] = e;
+        t->gap[L] = e;
     }
     t->gap[1] = t->lit[(unsigned char)'/'];
-    t->gap[GTZ_GAP_STRIDE + 1] = t->lit[(unsigned char)'\t'];
     for (uint32_t f = 1; f <= GTZ_CHUNK_CELLS; ++f) t->len4[f] = t->len[4 * f - 3];
     const uint32_t lit_w = std::max(std::max(ll[(unsigned char)'0'], ll[(unsigned char)'1']), std::max(ll[(unsigned char)'/'], ll[(unsigned char)'\t']));
     t->unit_ok = widest <= 27 && widest + lit_w <= 32 ? 1u : 0u;
@@ -190,6 +192,10 @@ inline bool gtz_build_tables(const uint32_t* hist, GtzTables* t)
         t->crc_unit_b[e] = crc32_bytes(t->crc_table, cells, sizeof cells) ^ full;
         cells[4 * j + 2] = '0';
     }
+    for (uint32_t P = 0; P < GTZ_CHUNK_CELLS / 2; ++P)
+        for (uint32_t v = 0; v < 16; ++v)
+            t->crc_nib[P * 16 + v] = ((v & 1u) ? t->crc_unit_a[2 * P + 1] : 0u) ^ ((v & 2u) ? t->crc_unit_b[2 * P + 1] : 0u) ^
+                                     ((v & 4u) ? t->crc_unit_a[2 * P] : 0u) ^ ((v & 8u) ? t->crc_unit_b[2 * P] : 0u);
     for (uint32_t j = 0; j < 1024; ++j) t->crc_shift_chunk[j] = crc_x8n((uint64_t)64 * j);
     for (uint32_t j = 0; j < 256; ++j) t->crc_shift_byte[j] = crc_x8n(j);
     return true;

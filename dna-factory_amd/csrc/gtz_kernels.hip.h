@@ -118,10 +118,10 @@ struct GtzShared {
 #ifdef DNAF_GTZ_PAD_LDS
     uint32_t pad_lds[DNAF_GTZ_PAD_LDS]; // occupancy experiments
 #endif
-    uint32_t codes[128 + 2 * GTZ_GAP_STRIDE + GTZ_CHUNK_CELLS + 8 + 32]; // lit, gap, len4, dist code tables; the symbol histogram in gtz_encode<true>
+    uint32_t codes[128 + GTZ_GAP_STRIDE + GTZ_CHUNK_CELLS + 8 + 32]; // lit, gap, len4, dist code tables; the symbol histogram in gtz_encode<true>
     uint32_t crc_table[256];
     uint32_t crc_base[GTZ_CHUNK_CELLS + 1];
-    uint32_t crc_unit_a[2 * GTZ_CHUNK_CELLS]; // first allele's units, then (crc_unit_b) the second allele's
+    uint32_t crc_nib[(GTZ_CHUNK_CELLS / 2) * 16]; // change of a chunk's CRC by the alleles of a pair of cells, [pairs before its end][4 alleles]
     // rows overlapping the member
     int32_t off[GTZ_MAX_ROWS + 2];     // row start relative to the member's first byte
     int32_t cs[GTZ_MAX_ROWS + 2];      // first cell's byte, relative to the member
@@ -139,11 +139,11 @@ struct GtzShared {
     uint32_t nr, n_items, ok, klass;
     __device__ __forceinline__ uint32_t* lit() { return codes; }
     __device__ __forceinline__ uint32_t* gap() { return codes + 128; }
-    __device__ __forceinline__ uint32_t* len4() { return codes + 128 + 2 * GTZ_GAP_STRIDE; }
-    __device__ __forceinline__ uint32_t* dist() { return codes + 128 + 2 * GTZ_GAP_STRIDE + GTZ_CHUNK_CELLS + 8; }
+    __device__ __forceinline__ uint32_t* len4() { return codes + 128 + GTZ_GAP_STRIDE; }
+    __device__ __forceinline__ uint32_t* dist() { return codes + 128 + GTZ_GAP_STRIDE + GTZ_CHUNK_CELLS + 8; }
     __device__ __forceinline__ uint32_t* hist() { return codes; }
 };
-static_assert(GTZ_NSYM <= 128 + 2 * GTZ_GAP_STRIDE, "the histogram reuses the code tables");
+static_assert(GTZ_NSYM <= 128 + GTZ_GAP_STRIDE + GTZ_CHUNK_CELLS + 8 + 32, "the histogram reuses the code tables");
 
 // 16 cells of the 2-bit stream starting at g
 __device__ __forceinline__ uint32_t gtz_window(const uint32_t* cells, uint32_t g)
@@ -429,12 +429,12 @@ __global__ __launch_bounds__(THREADS) GTZ_OCCUPANCY void gtz_encode(const GtzPar
         for (uint32_t t = tid; t < GTZ_NSYM; t += THREADS) s->hist()[t] = 0;
     } else {
         if (tid < 128) s->lit()[tid] = ct->lit[tid];
-        for (uint32_t t = tid; t < 2 * GTZ_GAP_STRIDE; t += THREADS) s->gap()[t] = ct->gap[t];
+        for (uint32_t t = tid; t < GTZ_GAP_STRIDE; t += THREADS) s->gap()[t] = ct->gap[t];
         if (tid < GTZ_CHUNK_CELLS + 8) s->len4()[tid] = ct->len4[tid];
         if (tid < 32) s->dist()[tid] = ct->dist[tid];
         if (tid < 256) s->crc_table[tid] = p.tables->crc_table[tid];
         if (tid <= GTZ_CHUNK_CELLS) s->crc_base[tid] = p.tables->crc_base[tid];
-        if (tid < GTZ_CHUNK_CELLS) { s->crc_unit_a[tid] = p.tables->crc_unit_a[tid]; s->crc_unit_a[GTZ_CHUNK_CELLS + tid] = p.tables->crc_unit_b[tid]; }
+        for (uint32_t t = tid; t < (GTZ_CHUNK_CELLS / 2) * 16; t += THREADS) s->crc_nib[t] = p.tables->crc_nib[t];
     }
     __syncthreads();
     if (!s->ok) { // a byte the literal table does not hold
@@ -539,23 +539,22 @@ __global__ __launch_bounds__(THREADS) GTZ_OCCUPANCY void gtz_encode(const GtzPar
                     }
                 }
 #endif
-                // CRC of the chunk's bytes from its cells: base pattern + one unit per '1' allele.  Only the set bits of the
-                // chunk's code words are visited (a tenth to a third of the 128 alleles), not every cell.
+                // CRC of the chunk's bytes from its cells: CRC is affine, so it is the CRC of n cells "0/0\t" XOR one unit per '1'
+                // allele, the unit depending on how far before the chunk's end the allele lies.  The cells are shifted so that
+                // the chunk's last cell is cell 63, and the units come four alleles at a time from a table by pairs of cells:
+                // 32 look-ups whatever the row (a loop over the set alleles took 12 instructions each, up to 90 of them in a
+                // chunk of a MAF-0.45 row).
                 const uint32_t n = k1 - k0;
                 uint32_t cc = s->crc_base[n];
-                {
+                if (DNAF_GTZ_EXP != 5) {
                     const GtzMask in = gtz_range(2u * ch.j0, 2u * ch.j1);
-                    uint64_t wlo = ch.lo & in.lo, whi = ch.hi & in.hi;
-                    const uint32_t* unit = s->crc_unit_a; // crc_unit_b follows it: [allele][cells before the end]
-                    const uint32_t last = ch.j1 - 1u;
-                    while (DNAF_GTZ_EXP != 5 && (wlo | whi)) {
-                        const bool low = wlo != 0;
-                        const uint64_t w = low ? wlo : whi;
-                        const uint32_t bit = (uint32_t)__builtin_ctzll(w);
-                        if (low) wlo &= wlo - 1; else whi &= whi - 1;
-                        const uint32_t j = (low ? 0u : 32u) + (bit >> 1);
-                        cc ^= unit[(bit & 1u) * GTZ_CHUNK_CELLS + (last - j)];
-                    }
+                    uint64_t vlo = ch.lo & in.lo, vhi = ch.hi & in.hi;
+                    const uint32_t sh = 2u * (64u - ch.j1); // 0 .. 126
+                    if (sh >= 64u) { vhi = vlo << (sh - 64u); vlo = 0; }
+                    else if (sh) { vhi = (vhi << sh) | (vlo >> (64u - sh)); vlo <<= sh; }
+                    const uint32_t w[4] = {(uint32_t)vlo, (uint32_t)(vlo >> 32), (uint32_t)vhi, (uint32_t)(vhi >> 32)};
+#pragma unroll
+                    for (uint32_t k = 0; k < 32u; ++k) cc ^= s->crc_nib[(31u - k) * 16u + ((w[k >> 3] >> (4u * (k & 7u))) & 15u)];
                 }
                 crc = cc;
                 nbytes = 4u * n;

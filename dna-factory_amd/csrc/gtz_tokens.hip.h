@@ -188,14 +188,14 @@ __device__ __forceinline__ GtzEvents gtz_find_matches(GtzShared* s, uint32_t i, 
 // lit(kind): 0 '0', 1 '1', 2 '/', 3 '\t'.   far(L, d): LZ77 match of L bytes at distance d.
 
 struct GtzBitCount {
-    const uint32_t* gap;   // LDS [2][GTZ_GAP_STRIDE]: gap length -> code, bit count in the low 5 bits
+    const uint32_t* gap;   // LDS [GTZ_GAP_STRIDE]: gap length -> code, bit count in the low 5 bits
     const uint32_t* len4;  // LDS: far match of f cells -> length code + extra bits
     const uint32_t* dist;  // LDS: distance symbol -> code
     uint32_t lit_n;        // 4 x 8 bits: code length of each literal kind
     uint32_t bits;
-    __device__ __forceinline__ uint32_t gap_entry(uint32_t L, uint32_t at) const { return gap[L + (at & 2u) * (GTZ_GAP_STRIDE / 2u)]; }
-    __device__ __forceinline__ void gap_lit(uint32_t L, uint32_t at, uint32_t value) { bits += (gap_entry(L, at) & 31u) + ((lit_n >> (8u * value)) & 0xFFu); }
-    __device__ __forceinline__ void gap_only(uint32_t L, uint32_t at) { bits += gap_entry(L, at) & 31u; }
+    __device__ __forceinline__ uint32_t gap_bits(uint32_t L, uint32_t at) const { return (L == 1u && (at & 2u)) ? lit_n >> 24 : gap[L] & 31u; }
+    __device__ __forceinline__ void gap_lit(uint32_t L, uint32_t at, uint32_t value) { bits += gap_bits(L, at) + ((lit_n >> (8u * value)) & 0xFFu); }
+    __device__ __forceinline__ void gap_only(uint32_t L, uint32_t at) { bits += gap_bits(L, at); }
     __device__ __forceinline__ void lit(uint32_t kind) { bits += (lit_n >> (8u * kind)) & 0xFFu; }
     __device__ __forceinline__ void far(uint32_t f, uint32_t d)
     {
@@ -244,7 +244,8 @@ struct GtzBitEmit {
         pos += n;
     }
     __device__ __forceinline__ void entry(uint32_t e) { put(e >> 5, e & 31u); }
-    __device__ __forceinline__ uint32_t gap_entry(uint32_t L, uint32_t at) const { return gap[L + (at & 2u) * (GTZ_GAP_STRIDE / 2u)]; }
+    // one byte behind an allele b is the tab's literal; everything else is in the table
+    __device__ __forceinline__ uint32_t gap_entry(uint32_t L, uint32_t at) const { return (L == 1u && (at & 2u)) ? lit_entry[3] : gap[L]; }
     __device__ __forceinline__ void lit(uint32_t kind)
     {
         entry(kind == 0u ? lit_entry[0] : kind == 1u ? lit_entry[1] : kind == 2u ? lit_entry[2] : lit_entry[3]);
@@ -327,9 +328,9 @@ __device__ __forceinline__ uint32_t gtz_count_bits(const GtzChunk& c, const GtzE
             if (low) rlo &= rlo - 1ull; else rhi &= rhi - 1ull;
             const uint32_t nx = gtz_next_bit(xlo, xhi, p + 1u);
             const uint32_t L = 2u * ((nx < 128u ? nx : end2) - p) - 1u;
-            // L >= 5 (the same entry in both halves of the table) -- except behind the last alleles of a chunk that has all
-            // 64 cells, whose end is no bit of the mask: three bytes, or one, the tab behind allele b of the last cell
-            bits += gap[L + (p & 1u) * GTZ_GAP_STRIDE] & 31u;
+            // L >= 5 -- except behind the last alleles of a chunk that has all 64 cells, whose end is no bit of the mask:
+            // three bytes, or one, the tab behind allele b of the last cell
+            bits += (L == 1u && (p & 1u)) ? lit_n >> 24 : gap[L] & 31u;
         }
     }
     // the gaps behind the far matches (they begin on a cell boundary: an even number of bytes, never two)

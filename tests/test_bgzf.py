@@ -213,19 +213,19 @@ def _gtz_tables(capi, hist):
     capi.lib.dnaf_gtz_tables_from_histogram(capi.ptr(h), None, 0, ctypes.byref(size))
     blob = np.zeros(size.value // 4, dtype=np.uint32)
     assert capi.lib.dnaf_gtz_tables_from_histogram(capi.ptr(h), capi.ptr(blob), size.value, ctypes.byref(size)) == 0
-    # lit, len, dist, eob + hdr_nbits, hdr, two pairs of u64 nibble tables, gap table (2 x 264), len4 (72), unit_ok, pad to 8 bytes
-    per = 256 + 256 + 32 + 2 + 64 + 8 + 528 + 72 + 2
+    # lit, len, dist, eob + hdr_nbits, hdr, two pairs of u64 nibble tables, gap table (264), len4 (72), unit_ok, pad to 8 bytes
+    per = 256 + 256 + 32 + 2 + 64 + 8 + 264 + 72 + 2
     classes = []
     for c in range(8):
         b = blob[c * per: (c + 1) * per]
         nib = b[610:618].view(np.uint64)
         classes.append({"lit": b[0:256], "len": b[256:512], "dist": b[512:544], "eob": int(b[544]), "hdr_nbits": int(b[545]),
-                        "hdr": b[546:610], "len_nb": nib[0:2], "dist_nb": nib[2:4], "gap": b[618:1146].reshape(2, 264), "len4": b[1146:1218],
-                        "unit_ok": int(b[1218])})
+                        "hdr": b[546:610], "len_nb": nib[0:2], "dist_nb": nib[2:4], "gap": b[618:882], "len4": b[882:954],
+                        "unit_ok": int(b[954])})
     rest = blob[8 * per:]
     t = {"cls": classes, "crc_table": rest[0:256], "crc_base": rest[256:321], "unit_a": rest[321:385], "unit_b": rest[385:449],
-         "shift_chunk": rest[449:1473], "shift_byte": rest[1473:1729]}
-    assert len(rest) in (1729, 1730)  # 8-byte struct alignment may add one pad word
+         "shift_chunk": rest[449:1473], "shift_byte": rest[1473:1729], "crc_nib": rest[1729:2241].reshape(32, 16)}
+    assert len(rest) in (2241, 2242)  # 8-byte struct alignment may add one pad word
     return t
 
 
@@ -269,14 +269,14 @@ def test_gtz_tables_make_valid_deflate_streams(capi):
             data.append(ord("1"))
             bits.put_entry(k["lit"][ord("1")])
         # the walk's units (gtz_tokens.hip.h): a gap of L repeating bytes is one table entry -- a match at distance 4 for L >= 3,
-        # the separator's literal for L = 1 ('/' in half 0, tab in half 1), nothing for L = 0 -- and a far match of f cells
-        # takes its length code from len4[f]
+        # the '/' literal for L = 1 (the tab behind an allele b is taken from the literal table), nothing for L = 0 -- and a
+        # far match of f cells takes its length code from len4[f]
         assert k["unit_ok"] == 1
-        for half, sep in ((0, ord("/")), (1, ord("\t"))):
+        for half, sep in ((0, ord("/")),):
             for L in range(0, 257):
                 if L == 2:
                     continue
-                entry = int(k["gap"][half][L])
+                entry = int(k["gap"][L])
                 assert (entry & 31) + max(int(k["lit"][ord("0")]) & 31, int(k["lit"][ord("1")]) & 31) <= 32
                 bits.put_entry(entry)
                 if L == 1:
@@ -314,6 +314,14 @@ def test_gtz_crc_of_a_chunk_from_its_cells(capi):
             if c & 2:
                 crc ^= int(t["unit_b"][e])
         assert crc == zlib.crc32(text)
+        # the same from the table by pairs of cells, as the kernel does it: cells shifted so that the last one is cell 63
+        v = 0
+        for j, c in enumerate(codes):
+            v |= int(c) << (2 * (64 - n + j))
+        crc2 = int(t["crc_base"][n])
+        for k in range(32):
+            crc2 ^= int(t["crc_nib"][31 - k][(v >> (4 * k)) & 15])
+        assert crc2 == zlib.crc32(text)
     assert int(t["crc_base"][0]) == 0
 
 
