@@ -107,16 +107,16 @@ def _generate_shard(device, seed, rng, mt_state, st, tb, row_lo, row_hi, rng_row
     from . import capi
     from .rowgen import RowGenerator
 
-    from concurrent.futures import ThreadPoolExecutor
-
-    with RowGenerator(device=device, seed=seed, rng=rng, mt_state=mt_state) as gen, ThreadPoolExecutor(max_workers=1) as writer:
+    with RowGenerator(device=device, seed=seed, rng=rng, mt_state=mt_state) as gen:
         gen.set_samples(st)
         gen.ctx.set_rng_divisor(rng_divisor)
         gen.set_snps(tb.slice(row_lo, row_hi), rng_row0=rng_row_lo)
         n = row_hi - row_lo
         q = gen.row_quantum * rng_divisor  # tiles begin where a wave of the stream and a group of rows sharing a stream row begin
         tile_rows = max(q, tile_rows // q * q)
-        pending = None  # the sink drains tile k on the writer thread while the GPU produces tile k+1
+        # the sink's I/O threads drain tiles k-2 .. k from the library's pinned staging buffers (four, used in turn) while the
+        # GPU generates, compresses and copies out tile k+1: a tile's write has to be over before the fourth fetch after its own
+        inflight = []
         trace = os.environ.get("DNAF_TRACE_TILES")  # per-tile seconds: GPU work, device -> host copy, wait for the writer
         for b in range(0, n, tile_rows):
             m = min(tile_rows, n - b)
@@ -124,32 +124,32 @@ def _generate_shard(device, seed, rng, mt_state, st, tb, row_lo, row_hi, rng_row
             gen.ctx.generate(b, m, capi.OUT_TEXT if host_bgzf and bed_sink is None else capi.OUT_TEXT | capi.OUT_PACKED)
             if bed_sink is not None:
                 bed_sink.write(gen.ctx.export_bed())  # .bed rows of this tile, straight from the packed matrix
-            if host_bgzf:
-                gen.ctx.sync()
-                t1 = time.time()
-                view, put = gen.ctx.fetch_text(), sink.write
-            else:
+            if not host_bgzf:
                 gen.ctx.bgzf_compress(reuse_tables=b > 0)
-                t1 = time.time()
-                view, put = gen.ctx.fetch_bgzf(), sink.write_members
+            else:
+                gen.ctx.sync()
+            t1 = time.time()
+            while len(inflight) >= 3:
+                inflight.pop(0).result()
             t2 = time.time()
-            # the library alternates two pinned staging buffers: tile k's stays valid through the fetch of tile k+1,
-            # so its write only has to finish before tile k+2 is fetched
-            if pending is not None:
-                pending.result()
-            pending = writer.submit(put, view)
+            if host_bgzf:
+                sink.write(gen.ctx.fetch_text())  # (copied into the compressor's blocks before write returns)
+            else:
+                fut = sink.write_members(gen.ctx.fetch_bgzf())
+                if fut is not None:
+                    inflight.append(fut)
             if trace:
-                print("tile %d: gpu %.3f s, copy %.3f s (%.0f MB), writer wait %.3f s" % (b // tile_rows, t1 - t0, t2 - t1, len(view) / 1e6, time.time() - t2), flush=True)
+                print("tile %d: gpu %.3f s, writer wait %.3f s, copy + hand-over %.3f s" % (b // tile_rows, t1 - t0, t2 - t1, time.time() - t2), flush=True)
             progress(m)
-        if pending is not None:
-            pending.result()
+        for fut in inflight:
+            fut.result()
 
 
 def _write_round_robin(path, header, st, tb, seed, rng, devices, compresslevel, tile_rows, threads, host_bgzf, mt_state, bed_path, progress):
     """Tile k of the table goes to device k mod G; the calling thread writes the tiles' BGZF members (and .bed rows) in
-    order as they arrive.  A device works one tile ahead of the writer: the library alternates two pinned staging
-    buffers, so a device's i-th fetch reuses the buffer of its (i-2)-th; the writer acknowledges every tile it has
-    written and a device collects the acknowledgement of tile i-2 before it fetches tile i."""
+    order as they arrive.  A device works up to three tiles ahead of the writer: the library uses four pinned staging
+    buffers in turn, so a device's i-th fetch reuses the buffer of its (i-4)-th; every tile's write (on the sink's I/O
+    threads) is acknowledged when it is over and a device collects the acknowledgement of tile i-4 before it fetches tile i."""
     import queue
 
     from . import bgzf, capi
@@ -182,7 +182,7 @@ def _write_round_robin(path, header, st, tb, seed, rng, devices, compresslevel, 
                     if not host_bgzf:
                         gen.ctx.bgzf_compress(reuse_tables=k >= G)
                     t1 = time.time()
-                    if k >= 2 * G:  # this fetch overwrites the staging buffer of this device's tile k - 2G: written by now?
+                    if k >= 4 * G:  # this fetch overwrites the staging buffer of this device's tile k - 4G: written by now?
                         while not acks[g].acquire(timeout=0.5):
                             if stop.is_set():
                                 return
@@ -212,10 +212,17 @@ def _write_round_robin(path, header, st, tb, seed, rng, devices, compresslevel, 
                 got, view, bed = slots[k % G].get()
                 if got != k:
                     raise view if got == -1 else RuntimeError("tile %d arrived in place of tile %d" % (got, k))
-                (f.write if host_bgzf else f.write_members)(view)
+                fut = None
+                if host_bgzf:
+                    f.write(view)  # (copied into the compressor's blocks before write returns)
+                else:
+                    fut = f.write_members(view)
+                if fut is None:
+                    acks[k % G].release()
+                else:
+                    fut.add_done_callback(lambda _f, g=k % G: acks[g].release())
                 if bed_f:
                     bed_f.write(bed)
-                acks[k % G].release()
                 progress(hi - lo)
     finally:
         stop.set()

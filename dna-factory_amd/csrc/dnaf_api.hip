@@ -134,8 +134,9 @@ struct dnaf_ctx {
     bool have_bed = false;
 
     // pinned host staging for device -> host copies at PCIe rate
-    void* h_pinned[2] = {nullptr, nullptr}; // alternate, so that one fetched range stays valid while the next is produced
-    uint64_t pinned_cap[2] = {0, 0};
+    static constexpr int N_PINNED = 4;      // used in turn: a fetched range stays valid through the next three fetches
+    void* h_pinned[N_PINNED] = {nullptr, nullptr, nullptr, nullptr};
+    uint64_t pinned_cap[N_PINNED] = {0, 0, 0, 0};
     int pinned_next = 0;
 
     // tuning
@@ -1321,7 +1322,7 @@ static int fetch_pinned(dnaf_ctx* c, const void* d_src, uint64_t n, const void**
 {
     HIP_TRY(c, hipSetDevice(c->device));
     const int k = c->pinned_next;
-    c->pinned_next ^= 1;
+    c->pinned_next = (k + 1) % dnaf_ctx::N_PINNED;
     if (n > c->pinned_cap[k]) {
         HIP_TRY(c, hipStreamSynchronize(c->stream));
         if (c->h_pinned[k]) (void)hipHostFree(c->h_pinned[k]);

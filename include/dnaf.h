@@ -200,10 +200,10 @@ int dnaf_packed_pitch_words(const dnaf_ctx* ctx, uint64_t* pitch_words);
 #define DNAF_BGZF_TEXT_DOMAIN 2u /* encode every member from the text (no genotype-domain members) */
 int dnaf_bgzf_compress(dnaf_ctx* ctx, uint32_t flags, uint64_t* n_bytes);
 int dnaf_read_bgzf(dnaf_ctx* ctx, void* dst, uint64_t dst_cap, uint64_t* n_bytes);
-/* The same data through the context's pinned staging buffer (DMA at PCIe rate instead of a pageable
- * copy): *host points at n_bytes bytes owned by the library.  Two staging buffers alternate, so the
- * pointer stays valid through the next dnaf_fetch_* call and is reused by the one after it (a writer
- * thread can drain range k while range k+1 is generated and fetched).  Synchronises. */
+/* The same data through the context's pinned staging buffers (DMA at PCIe rate instead of a pageable
+ * copy): *host points at n_bytes bytes owned by the library.  Four staging buffers are used in turn, so the
+ * pointer stays valid through the next THREE dnaf_fetch_* calls and is reused by the fourth (writer threads
+ * can drain ranges k-2 .. k while range k+1 is generated and fetched).  Synchronises. */
 int dnaf_fetch_bgzf(dnaf_ctx* ctx, const void** host, uint64_t* n_bytes);
 int dnaf_fetch_text(dnaf_ctx* ctx, const void** host, uint64_t* n_bytes);
 /* Summed device time of the encoder's kernels in the last dnaf_bgzf_compress (HIP events). */

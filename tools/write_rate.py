@@ -5,6 +5,7 @@ import numpy as np
 
 n = int(float(sys.argv[1])) if len(sys.argv) > 1 else 4 << 30
 path = sys.argv[2] if len(sys.argv) > 2 else "/tmp/write_rate.bin"
+chunk = int(float(sys.argv[3])) if len(sys.argv) > 3 else 1 << 30  # bytes per write() of the one-thread case
 buf = np.random.default_rng(1).integers(0, 256, n, dtype=np.uint8)
 mv = memoryview(buf)
 for threads in (1, 2, 4, 8, 16):
@@ -13,7 +14,7 @@ for threads in (1, 2, 4, 8, 16):
     if threads == 1:
         off = 0
         while off < n:
-            off += os.write(fd, mv[off:off + (1 << 30)])
+            off += os.write(fd, mv[off:off + chunk])
     else:
         step = (n + threads - 1) // threads
         def run(k):
@@ -24,5 +25,5 @@ for threads in (1, 2, 4, 8, 16):
         [x.start() for x in ths]; [x.join() for x in ths]
     dt = time.time() - t
     os.close(fd)
-    print("%2d thread(s): %.2f GB/s" % (threads, n / dt / 1e9), flush=True)
+    print("%2d thread(s)%s: %.2f GB/s" % (threads, " of %d MB writes" % (chunk >> 20) if threads == 1 else "", n / dt / 1e9), flush=True)
     os.remove(path)
