@@ -194,3 +194,80 @@ def test_numpy_legacy_choice_replay_is_numpy():
             assert np.array_equal(numpy.random.rand(3), follow)
     with pytest.raises(ValueError):
         capi.numpy_legacy_choice(3, 4)  # numpy's own error for a sample larger than the population
+
+
+def test_round_robin_writer_keeps_order_and_buffers(tmp_path, monkeypatch):
+    """cli._write_round_robin without a GPU: tiles dealt to three "devices" whose generators finish in random order and hand
+    over views of FOUR staging buffers used in turn (as the library does); the file must hold header + every tile's members
+    in table order, whatever the timing -- a device that fetched a tile before the writer had written the tile four
+    before it would overwrite bytes that are still to be written."""
+    import gzip
+    import random
+    import time
+
+    from dna_factory_amd import bgzf, cli, genome, rowgen
+    from dna_factory_amd.tables import SampleTable
+
+    tb = genome.synthetic_snp_table(3000, 0.01, np.random.RandomState(2))
+    st = SampleTable(np.zeros(8, dtype=np.uint8))
+
+    def tile_text(lo, hi):
+        return b"".join(b"row %d of the table\n" % j for j in range(lo, hi)) * 40
+
+    class FakeCtx:
+        def __init__(self, rnd):
+            self.rnd, self.bufs, self.k, self.lo, self.hi = rnd, [bytearray(1 << 20) for _ in range(4)], 0, 0, 0
+
+        def generate(self, b, m, what):
+            time.sleep(self.rnd.random() * 0.001)
+
+        def bgzf_compress(self, reuse_tables=False):
+            pass
+
+        def sync(self):
+            pass
+
+        def export_bed(self):
+            return b"bed[%d,%d)" % (self.lo, self.hi)
+
+        def fetch_bgzf(self):
+            text = tile_text(self.lo, self.hi)
+            blob = b"".join(bgzf.compress_block(text[i: i + bgzf.BLOCK_INPUT], 1) for i in range(0, len(text), bgzf.BLOCK_INPUT))
+            buf = self.bufs[self.k % 4]  # the fourth-next fetch reuses this buffer
+            self.k += 1
+            buf[: len(blob)] = blob
+            return memoryview(buf)[: len(blob)]
+
+    class FakeGen:
+        def __init__(self, device=0, seed=0, rng="philox", mt_state=None):
+            self.ctx = FakeCtx(random.Random(device))
+
+        def __enter__(self):
+            return self
+
+        def __exit__(self, *a):
+            for b in self.ctx.bufs:  # a context that is closed too early takes its buffers with it
+                b[:] = b"\xff" * len(b)
+
+        def set_samples(self, st):
+            pass
+
+        def set_snps(self, tb, rng_row0=0):
+            self.ctx.lo, self.ctx.hi = rng_row0, rng_row0 + len(tb)
+
+    monkeypatch.setattr(rowgen, "RowGenerator", FakeGen)
+    real_pwrite = bgzf._pwrite_all
+
+    def slow_pwrite(fd, mv, offset):  # a writer slower than the devices: they run ahead as far as the protocol lets them
+        time.sleep(0.004)
+        real_pwrite(fd, mv, offset)
+
+    monkeypatch.setattr(bgzf, "_pwrite_all", slow_pwrite)
+    path, bed = str(tmp_path / "out.vcf.gz"), str(tmp_path / "out.bed")
+    done = []
+    cli._write_round_robin(path, "##header\n", st, tb, 1, "philox", [0, 1, 2], 6, 100, 2, False, None, bed, done.append)
+    want = b"##header\n" + b"".join(tile_text(lo, min(3000, lo + 100)) for lo in range(0, 3000, 100))
+    assert gzip.open(path, "rb").read() == want
+    assert bgzf.block_sizes(path)[-1] == 28
+    assert open(bed, "rb").read() == cli.BED_MAGIC + b"".join(b"bed[%d,%d)" % (lo, lo + 100) for lo in range(0, 3000, 100))
+    assert sum(done) == 3000
