@@ -443,11 +443,10 @@ __global__ __launch_bounds__(THREADS) GTZ_OCCUPANCY void gtz_encode(const GtzPar
     }
     GTZ_STAMP(1); // cells and code tables in LDS
     // Key tables: for every segment of the g space the earliest and the latest position of every 5-cell key, 16-bit
-    // entries.  No atomics and no validity tests: the threads sweep the g space in ascending order -- "latest" is a plain
-    // store (the last step that holds the key wins), "earliest" a store where the entry is still empty.  Waves drift
-    // apart by a step or two and lanes of one step race, so both are approximate (some occurrence near the end / the
-    // beginning); the search verifies whatever it finds against the cells themselves and against the bounds of the
-    // source's row, so any position that is entered is harmless.  (Entering only positions whose cell differs from the
+    // entries.  No atomics, no reads and no validity tests: plain stores in ascending ("latest") and descending ("earliest")
+    // order; lanes of one step race, so both are approximate to the step (some occurrence near the end / the beginning);
+    // the search verifies whatever it finds against the cells themselves and against the bounds of the source's row, so
+    // any position that is entered is harmless.  (Entering only positions whose cell differs from the
     // cell before -- the only ones the search looks up -- was measured: slower and 1 % more bytes.)
     {
         for (uint32_t t = tid; t < (2 * GTZ_SEGS - 1) * GTZ_KEYS / 2; t += THREADS) { // [quarter][earliest, latest + 1][key], two entries per word
@@ -456,9 +455,10 @@ __global__ __launch_bounds__(THREADS) GTZ_OCCUPANCY void gtz_encode(const GtzPar
         }
         __syncthreads();
         const uint32_t total = DNAF_GTZ_EXP == 4 ? 0u : 16u * s->gw[nr];
-        // Every segment is swept by its own wave(s), in ascending steps of 256 positions, four consecutive ones per lane
-        // (one window read gives their keys; the four "earliest" entries are read together): a table has one writer in
-        // program order, so "latest" and "earliest" are exact to the 256 positions of a step, whatever the waves' pace.
+        // Every segment is swept by its own wave(s) in steps of 256 positions, four consecutive ones per lane (one window read
+        // gives their keys), with plain stores only: ascending for "latest", then descending for "earliest" -- the last
+        // writer of an entry is the highest / lowest position.  A table has one writer in program order, so both are exact
+        // to the 256 positions of a step, whatever the waves' pace.
         {
             constexpr uint32_t WPS = WAVES / GTZ_SEGS ? WAVES / GTZ_SEGS : 1u; // waves per segment (256 threads, 3 segments: one, the fourth wave rests)
             const uint32_t wave_ = tid >> 6, lane_ = tid & 63u;
@@ -466,17 +466,21 @@ __global__ __launch_bounds__(THREADS) GTZ_OCCUPANCY void gtz_encode(const GtzPar
             if (q < GTZ_SEGS) {
                 const uint32_t seg_lo = q * GTZ_SEG_CELLS, seg_hi = q + 1u < GTZ_SEGS ? min(total, seg_lo + GTZ_SEG_CELLS) : total;
                 uint16_t* tab = &s->tab16[(2u * q) * GTZ_KEYS];
-                for (uint32_t g0 = seg_lo + 256u * sub + 4u * lane_; g0 < seg_hi; g0 += 256u * WPS) {
-                    const uint32_t w = gtz_window(s->cells, g0);
-                    uint32_t key[4], seen[4];
+                // "latest": ascending, plain stores; "earliest": descending, plain stores (the last writer is the lowest position)
+                if (q + 1u < GTZ_SEGS)
+                    for (uint32_t g0 = seg_lo + 256u * sub + 4u * lane_; g0 < seg_hi; g0 += 256u * WPS) {
+                        const uint32_t w = gtz_window(s->cells, g0);
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) { key[k] = (w >> (2 * k)) & (GTZ_KEYS - 1u); seen[k] = tab[key[k]]; }
+                        for (int k = 0; k < 4; ++k) tab[GTZ_KEYS + ((w >> (2 * k)) & (GTZ_KEYS - 1u))] = (uint16_t)(g0 + (uint32_t)k + 1u);
+                    }
+                if (seg_lo < seg_hi) { // (a member shorter than this segment's start has nothing here)
+                    const uint32_t steps = (seg_hi - seg_lo + 256u * WPS - 1u) / (256u * WPS);
+                    for (uint32_t st = steps; st-- > 0u;) {
+                        const uint32_t g0 = seg_lo + 256u * (st * WPS + sub) + 4u * lane_;
+                        if (g0 >= seg_hi) continue;
+                        const uint32_t w = gtz_window(s->cells, g0);
 #pragma unroll
-                    for (int k = 3; k >= 0; --k) // descending: of equal keys in this group the lowest position stays
-                        if (seen[k] == 0xFFFFu) tab[key[k]] = (uint16_t)(g0 + (uint32_t)k);
-                    if (q + 1u < GTZ_SEGS) {
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) tab[GTZ_KEYS + key[k]] = (uint16_t)(g0 + (uint32_t)k + 1u);
+                        for (int k = 3; k >= 0; --k) tab[(w >> (2 * k)) & (GTZ_KEYS - 1u)] = (uint16_t)(g0 + (uint32_t)k);
                     }
                 }
             }
