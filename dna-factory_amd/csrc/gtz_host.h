@@ -34,8 +34,6 @@ struct GtzClassTables {
     uint32_t eob;
     uint32_t hdr_nbits;
     uint32_t hdr[GTZ_HDR_WORDS];
-    uint64_t len_nb[2];  // code length of length symbol 257 + n at nibble n (the bit-count pass works from registers)
-    uint64_t dist_nb[2]; // code length of distance symbol n at nibble n
     // gap[L]: the L bytes between two events of a chunk (gtz_tokens.hip.h), every one repeating the byte four back:
     // L >= 3 one match (length code + extra bits + the code of distance 4), L = 0 nothing; L = 1 is the separator's
     // literal, '/' behind an allele a (this table) or the tab behind an allele b (the kernel takes lit['\t']).  At most 27 bits.
@@ -122,9 +120,6 @@ inline void gtz_build_class(const uint64_t* litlen_hist, const uint64_t* dist_hi
     for (uint32_t f = 1; f <= GTZ_CHUNK_CELLS; ++f) t->len4[f] = t->len[4 * f - 3];
     const uint32_t lit_w = std::max(std::max(ll[(unsigned char)'0'], ll[(unsigned char)'1']), std::max(ll[(unsigned char)'/'], ll[(unsigned char)'\t']));
     t->unit_ok = widest <= 27 && widest + lit_w <= 32 ? 1u : 0u;
-    t->len_nb[0] = t->len_nb[1] = t->dist_nb[0] = t->dist_nb[1] = 0;
-    for (uint32_t s = 0; s < 29; ++s) t->len_nb[s >> 4] |= (uint64_t)ll[257 + s] << (4 * (s & 15));
-    for (uint32_t s = 0; s < 30; ++s) t->dist_nb[s >> 4] |= (uint64_t)dl[s] << (4 * (s & 15));
 
     // header: BFINAL=1, BTYPE=10, HLIT=286, HDIST=30, code lengths run-length coded with their own Huffman code
     std::vector<uint8_t> all(ll);

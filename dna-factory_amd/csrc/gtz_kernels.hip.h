@@ -3,26 +3,30 @@
 //
 // A member (61,440 text bytes) that lies in biallelic autosome rows is a known function of the packed
 // matrix: row r's text is its prefix followed by cells "a/b\t" (the last one ends in "\n"), 4 bytes per
-// sample.  One 256-thread workgroup encodes one member:
+// sample.  One workgroup encodes one member, one thread one ITEM of it -- a 64-cell chunk (256 text bytes) or
+// the literal span between two rows' cell regions (last cell of a row, "\n", the next row's fixed columns);
+// 256 threads where rows are long, 512 where short rows make more items (the host picks):
 //
 //   1. the rows that overlap the member are laid out in LDS ("g space": their 2-bit cells back to back,
-//      word-aligned per row), 960 words instead of 61 KB of text;
-//   2. every 5-cell key (10 bits) is entered into direct-indexed tables -- earliest and latest position
-//      per quarter of the member -- with LDS atomics;
-//   3. each thread owns one 64-cell chunk (256 text bytes), held in four registers.  Search: the lanes of
-//      a wave step together from one "break" (a cell that differs from its predecessor) to the next,
-//      look the key up, extend the candidates by XOR / count-trailing-zeros on the 2-bit stream and
-//      record an LZ77 match when it replaces enough literals.  Walk: the chunk becomes tokens -- the
-//      recorded matches, matches at distance 4 for repeating bytes, literals for the rest; the gaps
-//      between rows' cell regions (last cell of a row, "\n", the next row's fixed columns) are literal
-//      spans;
-//   4. bit counts are scanned, the walk is repeated into an LDS image of the whole member (gzip header,
-//      deflate block, CRC-32, ISIZE) and the image is written to the member's staging slot;  the member
-//      CRC comes from the cells by linearity of the CRC (per-cell unit tables), never from text bytes.
+//      word-aligned per row), 960 words instead of 61 KB of text; the spans' bytes are staged in LDS too;
+//   2. key tables: earliest and latest position of every 5-cell key (10 bits) per segment of the g space,
+//      each table written by one wave with plain stores in ascending / descending order -- no atomics;
+//   3. search (gtz_tokens.hip.h): a thread steps from one "break" of its chunk (a cell that differs from
+//      its predecessor) to the next, looks the key up, compares two candidates by XOR / count-trailing-zeros
+//      on 16-cell windows read from LDS and takes an LZ77 ("far") match when it covers enough cells and
+//      breaks.  The matches stay in registers (masks of their first alleles and ends, a queue of distances);
+//   4. the chunk's deflate bits are counted by mask arithmetic, the counts scanned over the workgroup, and
+//      one walk over the chunk's events (breaking alleles and far matches: [gap before it][own symbol], the
+//      gap one table entry) writes the bits into an LDS image of the whole member (gzip header, deflate
+//      block, CRC-32, ISIZE), which goes to the member's staging slot.  The member CRC comes from the cells
+//      by linearity of the CRC (a table by pairs of cells), never from text bytes.
 //
-// bgzf_scan turns sizes into offsets and gtz_compact moves the members to their place in the stream.
-// Members the kernel does not take (other chromosome classes, multi-allelic rows, more than GTZ_MAX_ROWS
-// rows, a body above the slot size) are left to the text-domain encoder (bgzf_kernels.hip.h).
+// Seven workgroups share a CU (22.8 KB of LDS, 72 registers): the kernel was bound by latency until the
+// match lists left LDS; now its vector units are busy (profiles/r03_gtz_*).
+// bgzf_scan_totals / _apply turn sizes into offsets and gtz_compact moves the members to their place in the
+// stream.  Members the kernel does not take (other chromosome classes, multi-allelic rows, more than
+// GTZ_MAX_ROWS rows, more items than threads, a body above the image size, a class whose codes do not fit
+// the walk's 32-bit units) are left to the text-domain encoder (bgzf_kernels.hip.h).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -49,7 +53,6 @@ __device__ __forceinline__ uint32_t gtz_segment(uint32_t g)
     return GTZ_SEGS == 4 ? min(g >> 12, 3u) : (g >= GTZ_SEG_CELLS ? 1u : 0u) + (g >= 2u * GTZ_SEG_CELLS ? 1u : 0u);
 }
 constexpr uint32_t GTZ_MAX_ROWS = 16;     // rows overlapping one member
-constexpr uint32_t GTZ_MAX_CHUNKS = 240 + 2 * GTZ_MAX_ROWS;
 constexpr uint32_t GTZ_MAX_FAR = 12;      // LZ77 matches recorded per chunk (64 cells / 5)
 constexpr uint32_t GTZ_CELL_WORDS = BGZF_IN / 64 + 2 * GTZ_MAX_ROWS + 8;
 constexpr uint32_t GTZ_STRIDE = 16384;    // staging slot of a member (global memory)
@@ -160,31 +163,9 @@ struct GtzChunk {
     uint32_t j0, j1;   // cells [j0, j1) of the 64-cell grid belong to the item
     bool head;         // cell j0 is the first cell of the row's region: nothing before it to refer to
     __device__ __forceinline__ uint32_t code(uint32_t j) const { return (uint32_t)((j < 32u ? lo >> (2u * j) : hi >> (2u * j - 64u)) & 3u); }
-    __device__ __forceinline__ uint32_t x(uint32_t j) const { return (uint32_t)((j < 32u ? xlo >> (2u * j) : xhi >> (2u * j - 64u)) & 3u); }
-    // 16 cells from j (cells past the chunk read as 0)
-    __device__ __forceinline__ uint32_t window(uint32_t j) const
-    {
-        if (j >= 32u) return j >= 64u ? 0u : (uint32_t)(hi >> (2u * j - 64u));
-        uint64_t v = lo >> (2u * j);
-        if (j) v |= hi << (64u - 2u * j);
-        return (uint32_t)v;
-    }
 };
 
 __device__ __forceinline__ uint64_t gtz_low_mask(uint32_t nbits) { return nbits >= 64u ? ~0ull : (1ull << nbits) - 1ull; }
-
-// first cell >= pos whose break bit is set (64 if none); b has one bit per cell at even positions
-__device__ __forceinline__ uint32_t gtz_next_break(uint64_t blo, uint64_t bhi, uint32_t pos)
-{
-    if (pos < 32u) {
-        const uint64_t t = blo & ~gtz_low_mask(2u * pos);
-        if (t) return (uint32_t)__builtin_ctzll(t) >> 1;
-        return bhi ? 32u + ((uint32_t)__builtin_ctzll(bhi) >> 1) : 64u;
-    }
-    if (pos >= 64u) return 64u;
-    const uint64_t t = bhi & ~gtz_low_mask(2u * pos - 64u);
-    return t ? 32u + ((uint32_t)__builtin_ctzll(t) >> 1) : 64u;
-}
 
 __device__ __forceinline__ GtzChunk gtz_load_chunk(const GtzShared* s, uint32_t i, uint32_t c64, uint32_t k0, uint32_t k1)
 {
