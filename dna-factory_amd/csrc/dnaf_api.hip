@@ -1215,6 +1215,11 @@ int dnaf_bgzf_compress(dnaf_ctx* c, uint32_t flags, uint64_t* n_bytes)
             HIP_TRY(c, hipGetLastError());
             HIP_TRY(c, hipMemcpyAsync(h, c->d_gtz_hist, sizeof h, hipMemcpyDeviceToHost, c->stream));
             HIP_TRY(c, hipStreamSynchronize(c->stream));
+            // the histogram kernel's self-check of the encoder's bit count (spare slot of every class, gtz_kernels.hip.h)
+            for (uint32_t k = 0; k < dnaf::GTZ_NCLASS; ++k)
+                if (h[k * dnaf::GTZ_NSYM + dnaf::GTZ_NSYM - 1])
+                    return fail(c, DNAF_ERR_STATE, "dnaf_bgzf_compress: the encoder's bit count disagrees with its token walk on %u sampled chunks (class %u): "
+                                "refusing to write members", h[k * dnaf::GTZ_NSYM + dnaf::GTZ_NSYM - 1], k);
             static thread_local dnaf::GtzTables gt;
             if (!dnaf::gtz_build_tables(h, &gt)) return fail(c, DNAF_ERR_UNSUPPORTED, "dnaf_bgzf_compress: block header does not fit");
             HIP_TRY(c, hipMemcpy(c->d_gtz_tables, &gt, sizeof gt, hipMemcpyHostToDevice));

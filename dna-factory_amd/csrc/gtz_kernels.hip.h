@@ -408,6 +408,9 @@ __global__ __launch_bounds__(THREADS) GTZ_OCCUPANCY void gtz_encode(const GtzPar
     }
     if (HIST) {
         for (uint32_t t = tid; t < GTZ_NSYM; t += THREADS) s->hist()[t] = 0;
+        // self-check of the bit count (below): a made-up table of gap lengths, in the space the CRC table has in the other form
+        // (entry 1 is the '/' literal, as in the real tables: 7 bits in the made-up literal lengths 3, 5, 7, 11)
+        for (uint32_t t = tid; t < GTZ_GAP_STRIDE; t += THREADS) s->crc_nib[t] = t == 0u ? 0u : t == 1u ? 7u : (t * 37u + 11u) % 27u + 1u;
     } else {
         if (tid < 128) s->lit()[tid] = ct->lit[tid];
         for (uint32_t t = tid; t < GTZ_GAP_STRIDE; t += THREADS) s->gap()[t] = ct->gap[t];
@@ -510,6 +513,15 @@ __global__ __launch_bounds__(THREADS) GTZ_OCCUPANCY void gtz_encode(const GtzPar
             if (HIST) {
                 GtzSymbolCount hs{s->hist()};
                 gtz_walk(ch, evs, hs);
+                // Self-check on the sampled members, in every run: the chunks' bit offsets come from gtz_count_bits, mask
+                // arithmetic that must agree with the walk that writes the bits.  Both are run here with a made-up code-length
+                // table (the real ones do not exist yet -- this kernel collects the histogram they are built from; far matches'
+                // own symbols count 0 on both sides); a disagreement is counted in a spare slot of the histogram and the host
+                // refuses to go on (dnaf_bgzf_compress).
+                const uint32_t fake_lit = 0x0B070503u;
+                GtzBitCount cnt{s->crc_nib, s->crc_nib, s->crc_nib, fake_lit, 0};
+                gtz_walk(ch, evs, cnt);
+                if (cnt.bits - cnt.far_seen != gtz_count_bits(ch, evs, s->crc_nib, fake_lit)) atomicAdd(&p.hist[klass * GTZ_NSYM + GTZ_NSYM - 1u], 1u);
             } else {
                 bits = DNAF_GTZ_EXP == 3 ? 150u : gtz_count_bits(ch, evs, s->gap(), lit_bits);
 #ifdef DNAF_GTZ_CHECK_COUNT

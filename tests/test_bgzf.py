@@ -440,3 +440,41 @@ def test_bgzf_random_shapes_and_ranges(capi):
             text, _, _ = g.generate(b, m, text=True, packed=False)
             blob, n_text = g.generate_bgzf(b, m)
             assert n_text == len(text) and gzip.decompress(blob.tobytes()) == text.tobytes(), (case, S, n, b, m)
+
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.gpu
+def test_bit_count_self_check_fires_on_a_wrong_count(tmp_path):
+    """The chunks' bit offsets in a member come from gtz_count_bits (mask arithmetic), the bits from gtz_walk; the histogram
+    kernel runs both on every sampled chunk and dnaf_bgzf_compress refuses to go on when they disagree.  A build whose count
+    is wrong in one rare case (-DDNAF_GTZ_BREAK_COUNT: chunks of 64 cells whose last allele is an event) must be refused --
+    and is, instead of writing members that do not inflate."""
+    import shutil
+    import subprocess
+    import sys
+
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc on this box")
+    csrc = os.path.join(REPO, "dna-factory_amd", "csrc")
+    lib = str(tmp_path / "libdnaf_broken_count.so")
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DDNAF_GTZ_BREAK_COUNT", "-o", lib,
+                           "dnaf_api.hip"], cwd=csrc)
+    script = (
+        "import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import test_bgzf as t\n"
+        "from dna_factory_amd import capi\n"
+        "from dna_factory_amd.rowgen import RowGenerator\n"
+        "tb, st = t._sorted_case(20000, 64, seed=1)\n"
+        "with RowGenerator(device=0, seed=11) as g:\n"
+        "    g.set_samples(st); g.set_snps(tb)\n"
+        "    try:\n"
+        "        g.generate_bgzf()\n"
+        "    except capi.DnafError as e:\n"
+        "        print('REFUSED', e)\n"
+        "    else:\n"
+        "        print('WROTE MEMBERS')\n" % (REPO, os.path.join(REPO, "tests")))
+    r = subprocess.run([sys.executable, "-c", script], env=dict(os.environ, DNAF_LIB=lib), capture_output=True, text=True, timeout=300)
+    assert "REFUSED" in r.stdout and "bit count disagrees" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
