@@ -56,7 +56,8 @@ def parse_cmd_args(args):
     p.add_argument("--threads", type=int, default=0, help="BGZF compression threads per shard (0 = auto)")
     p.add_argument("--host-bgzf", action="store_true",
                    help="compress on the host with zlib at level -z (like the reference) instead of the on-GPU BGZF "
-                        "encoder, which ignores -z")
+                        "encoder, which ignores -z: smaller files (zlib -6: 0.23 B/genotype against 0.31 at 20k samples; "
+                        "1.8 x smaller at 200 samples), at zlib's speed")
     p.add_argument("--plink", action="store_true",
                    help="also write population.bed and population.bim (PLINK 1 binary genotypes made on the GPU from the "
                         "2-bit matrix; population.fam is the matching .fam), so PLINK need not convert the VCF")
@@ -295,8 +296,8 @@ def generate_population(args):
     if not devices or min(devices) < 0:
         raise SystemExit("--devices needs at least one GPU id (>= 0), got %r" % args.devices)
     if not args.host_bgzf and args.compression_level != 6:
-        # the reference hands -z to zlib; the on-GPU encoder has one setting (about zlib -6's size)
-        print("note: -z %d does not apply to the on-GPU BGZF encoder (output is about as small as zlib -6); "
+        # the reference hands -z to zlib; the on-GPU encoder has one setting (between zlib -1 and -6 in size)
+        print("note: -z %d does not apply to the on-GPU BGZF encoder (its output lies between zlib -1 and zlib -6 in size); "
               "use --host-bgzf to compress with zlib at that level like the reference" % args.compression_level, flush=True)
     t_start = time.time()
     seed = args.seed if args.seed is not None else int(datetime.now().strftime("%H%M%S"))  # pop_factory.py:235
