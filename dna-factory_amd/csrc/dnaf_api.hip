@@ -810,6 +810,11 @@ int dnaf_generate(dnaf_ctx* c, uint64_t row_begin, uint64_t n_rows, uint32_t wha
     p.key0 = (uint32_t)c->seed;
     p.key1 = (uint32_t)(c->seed >> 32);
     p.S = c->S; p.G = c->G; p.W = c->W;
+    if (c->G) { // rowmix_kernel's divisions, done here once instead of by every wave
+        p.mix_gmagic = (uint32_t)std::min<uint64_t>(0x100000000ull / c->G, 0xFFFFFFFFull);
+        p.mix_step_rows = 64u / c->G;
+        p.mix_step_groups = 64u % c->G;
+    }
     // Two forms of the kernel.  Rows of at least 256 groups in a range with enough rows to fill the GPU one run per wave:
     // the line-owning form (rowrun_kernels.hip.h), a wave per run of whole rows, every 128-byte line of the text has one
     // writer.  Otherwise (short rows, or a few very long ones): a wave per row segment (rowgen_kernels.hip.h).
@@ -843,7 +848,7 @@ int dnaf_generate(dnaf_ctx* c, uint64_t row_begin, uint64_t n_rows, uint32_t wha
         }
         while (rpw > 1 && n_rows / rpw < 16384) rpw /= 2;
         if (c->force_rpw) rpw = std::min<uint32_t>(c->force_rpw, 64u);
-        if (c->prefix_stride > 48u) rpw = std::min<uint32_t>(rpw, dnaf::MIX_PFX_BYTES / c->prefix_stride); // the run's fixed columns must fit their LDS cache
+        if (c->prefix_stride) rpw = std::min<uint32_t>(rpw, dnaf::MIX_PFX_BYTES / c->prefix_stride); // the run's fixed columns must fit their LDS cache
     }
     p.rows_per_wave = rpw;
     const uint64_t items = (use_runs || use_mix) ? (n_rows + rpw - 1) / rpw : n_rows * p.nseg;

@@ -55,6 +55,8 @@ struct GenParams {
     uint32_t rows_per_wave;    // rowrun_kernel: whole rows per wave
     uint32_t prefix_stride;    // rowmix_kernel: bytes per row in prefix_fixed (multiple of 16, <= 64); 0: no such copy
     const uint8_t* prefix_fixed; // [table rows][prefix_stride] the rows' fixed columns at a fixed stride
+    uint32_t mix_gmagic;       // rowmix_kernel: min(floor(2^32 / G), 2^32 - 1), for q / G by one multiply-high (divmod_small)
+    uint32_t mix_step_rows, mix_step_groups; // rowmix_kernel: a trip ahead = 64 groups = 64 / G rows + 64 mod G groups
 };
 
 // RNG row (relative to rng_row0) of table row j.  rng_div > 1 reproduces the reference's forked workers, which all draw

@@ -81,9 +81,13 @@ __global__ DNAF_MIX_BOUNDS void rowmix_kernel(const GenParams p)
 #endif
     __shared__ u32x4_t cell_lut[256];
     __shared__ __attribute__((aligned(16))) uint8_t pk_stage[4][MIX_STAGE];
-    __shared__ __attribute__((aligned(16))) u32x4_t xs_all[4][64]; // per row of the run: the four folded Philox constants
-    __shared__ __attribute__((aligned(8))) u32x2_t ts_all[4][64];     // its threshold and where its cells start (cells_rel)
+    __shared__ __attribute__((aligned(16))) u32x4_t rows_all[4][128]; // per row of the run, 32 bytes (MixRow): the four folded Philox
+                                                                     // constants; its threshold and where its cells start (cells_rel)
     __shared__ __attribute__((aligned(16))) uint8_t pfx_all[4][MIX_PFX_BYTES];
+#ifdef DNAF_MIX_LDS_PAD
+    __shared__ uint8_t lds_pad[DNAF_MIX_LDS_PAD]; // occupancy experiments: fewer workgroups per CU
+    if (p.n_rows == ~0ull) lds_pad[threadIdx.x] = 1;
+#endif
     if (TEXT) {
         const uint32_t t = threadIdx.x;
         const u32x4_t e = {CELL00 + (t & 1u) + ((t & 2u) << 15), CELL00 + ((t >> 2) & 1u) + ((t & 8u) << 13),
@@ -101,8 +105,7 @@ __global__ DNAF_MIX_BOUNDS void rowmix_kernel(const GenParams p)
     const uint32_t nrun = (uint32_t)min((uint64_t)R, p.n_rows - j0);
     const uint32_t G = p.G, S = p.S;
     const uint32_t g_stop = PACKED ? p.W * 4u : G;
-    LDS_PTR(u32x4_t) xtab = (LDS_PTR(u32x4_t))xs_all[threadIdx.x >> 6];
-    LDS_PTR(u32x2_t) ttab = (LDS_PTR(u32x2_t))ts_all[threadIdx.x >> 6];
+    LDS_PTR(u32x4_t) rtab = (LDS_PTR(u32x4_t))rows_all[threadIdx.x >> 6]; // one address per lane and trip: entry 2 row, its second half 16 bytes on
 
     SegCtx c;
     c.lut = (const LDS_PTR(u32x4_t))cell_lut;
@@ -139,8 +142,8 @@ __global__ DNAF_MIX_BOUNDS void rowmix_kernel(const GenParams p)
         e.x0 = rc.x0; e.x1 = rc.x1; e.x2 = rc.x2; e.x3 = rc.x3;
         e.t0 = myrec.thr[0]; e.cells_rel = my_rel + myrec.prefix_len; e.pad0 = e.pad1 = 0;
         if (lane_id < nrun) {
-            xtab[lane_id] = u32x4_t{e.x0, e.x1, e.x2, e.x3};
-            ttab[lane_id] = u32x2_t{e.t0, e.cells_rel};
+            rtab[2u * lane_id] = u32x4_t{e.x0, e.x1, e.x2, e.x3};
+            *reinterpret_cast<LDS_PTR(u32x2_t)>(rtab + 2u * lane_id + 1u) = u32x2_t{e.t0, e.cells_rel};
         }
     }
     MIX_STAMP(1); // records loaded, row table written
@@ -162,9 +165,11 @@ __global__ DNAF_MIX_BOUNDS void rowmix_kernel(const GenParams p)
 #endif
     MIX_STAMP(2); // fixed columns in LDS
     const RowKeys keys = make_row_keys(p.key0, p.key1);
-    const uint32_t gmagic = (uint32_t)min(0x100000000ull / G, 0xFFFFFFFFull);
+    const uint32_t gmagic = p.mix_gmagic;
     const uint32_t nvalid_last = FULL4 ? 4u : S - 4u * (G - 1u); // samples in a row's last group, 1 .. 4
-    const uint32_t step_rows = 64u / G, step_groups = 64u - step_rows * G; // a trip ahead: 64 groups = step_rows rows + step_groups
+    const uint32_t step_groups = p.mix_step_groups; // a trip ahead: 64 groups = step_rows rows + step_groups (divided on the host)
+    uint32_t neg_step = 0u - (p.mix_step_rows + 1u); // in a vector register for the loop's life: v_subb reads its one scalar, vcc, already
+    asm volatile("" : "+v"(neg_step));
     const uint32_t fix = 0x0A000000u - 0x09000000u; // '\n' instead of the last '\t'
 
     uint32_t r = 0;
@@ -207,8 +212,8 @@ __global__ DNAF_MIX_BOUNDS void rowmix_kernel(const GenParams p)
         uint32_t row0, g0;
         bool live0;
         coords(0u, row0, g0, live0);
-        u32x4_t xs0 = xtab[row0];
-        u32x2_t ts0 = ttab[row0];
+        u32x4_t xs0 = rtab[2u * row0];
+        u32x2_t ts0 = *reinterpret_cast<LDS_PTR(u32x2_t)>(rtab + 2u * row0 + 1u);
         bool have_prev = false, live_prev = false, last_prev = false;
         u32x4_t w_prev = {0, 0, 0, 0};
         uint32_t off_prev = 0;
@@ -232,14 +237,19 @@ __global__ DNAF_MIX_BOUNDS void rowmix_kernel(const GenParams p)
         auto trip = [&](uint32_t qb, uint32_t row0, uint32_t g0, bool live0, const u32x4_t& xs0, const u32x2_t& ts0, uint32_t& row1,
                         uint32_t& g1, bool& live1, u32x4_t& xs1, u32x2_t& ts1) {
             if (qb + 64u < n) { // wave-uniform
-                // one trip on: no division, the lane's group moves by 64 mod G and its row by 64 / G (+ 1 when the group wraps)
-                const uint32_t gs = g0 + step_groups;
-                const bool wrap = gs >= G;
-                g1 = wrap ? gs - G : gs;
-                row1 = row0 + step_rows + (wrap ? 1u : 0u);
-                live1 = qb + 64u + lane < n;
-                xs1 = xtab[row1];
-                ts1 = ttab[row1];
+                // one trip on: no division, the lane's group moves by 64 mod G and its row by 64 / G (+ 1 when the group wraps);
+                // four instructions: the borrow of gs - G selects the group and is subtracted from row0 + 64 / G + 1
+                uint32_t gs, gt;
+                asm("v_add_u32 %[gs], %[sg], %[g0]\n\t"
+                    "v_subrev_co_u32 %[gt], vcc, %[G], %[gs]\n\t"
+                    "v_cndmask_b32 %[g1], %[gt], %[gs], vcc\n\t"
+                    "v_subb_co_u32 %[row1], vcc, %[row0], %[ns], vcc"
+                    : [gs] "=&v"(gs), [gt] "=&v"(gt), [g1] "=&v"(g1), [row1] "=&v"(row1)
+                    : [sg] "s"(step_groups), [G] "s"(G), [g0] "v"(g0), [row0] "v"(row0), [ns] "v"(neg_step)
+                    : "vcc");
+                live1 = row1 < e; // the groups of the stretch's rows are all live, those of "rows" past it are not
+                xs1 = rtab[2u * row1];
+                ts1 = *reinterpret_cast<LDS_PTR(u32x2_t)>(rtab + 2u * row1 + 1u);
             }
             if (TEXT && pfx_cached) {
                 // fixed columns of the rows that begin in this trip (pop_factory.py:503-507, formatted on the host)
@@ -247,13 +257,18 @@ __global__ DNAF_MIX_BOUNDS void rowmix_kernel(const GenParams p)
                     const uint32_t plen = __builtin_amdgcn_readlane(my_plen, next_row);
                     const uint32_t rel = __builtin_amdgcn_readlane(my_rel, next_row);
                     const uint32_t at = pstride ? next_row * pstride : __builtin_amdgcn_readlane(my_poff, next_row) - pfx0;
-                    for (uint32_t i = lane; i < plen; i += 64) run_text[rel + i] = pfx[at + i];
+                    if (pstride) { // (wave-uniform) at most pstride <= 64 bytes: one predicated byte copy, no loop to set up
+                        if (lane < plen) run_text[rel + lane] = pfx[at + lane];
+                    } else {
+#pragma clang loop unroll(disable)
+                        for (uint32_t i = lane; i < plen; i += 64) run_text[rel + i] = pfx[at + i];
+                    }
                     ++next_row;
                     next_q += G;
                 }
             }
-            const uint64_t P = (uint64_t)PHILOX_M0 * (2u * g0);
-            uint32_t pk = group_code_lanes(P, xs0.x, xs0.y, xs0.z, xs0.w, ts0.x, keys);
+            const uint64_t P = (uint64_t)PHILOX_M0 * g0;
+            uint32_t pk = group_code_lanes_g(P, xs0.x, xs0.y, xs0.z, xs0.w, ts0.x, keys);
             const bool last = g0 == G - 1u;
             if (TEXT) {
                 if (have_prev) store_prev();

@@ -113,9 +113,12 @@ __device__ __forceinline__ RowKeys make_row_keys(uint32_t k0, uint32_t k1)
     return k;
 }
 
-#define DNAF_GROUP_ASM \
-        "v_lshl_add_u64 v[40:41], %[P], 0, %[offb]\n\t" \
-        "v_lshl_add_u64 v[54:55], %[P], 0, %[offa]\n\t" \
+#define DNAF_GROUP_ASM DNAF_GROUP_HEAD("0") DNAF_GROUP_BODY
+// first-round products of the two blocks: (P << shift) + the wave's share
+#define DNAF_GROUP_HEAD(shift) \
+        "v_lshl_add_u64 v[40:41], %[P], " shift ", %[offb]\n\t" \
+        "v_lshl_add_u64 v[54:55], %[P], " shift ", %[offa]\n\t"
+#define DNAF_GROUP_BODY \
         "v_xor_b32 v46, %[x0], v41\n\t" \
         "v_xor_b32 v60, %[x0], v55\n\t" \
         "v_mad_u64_u32 v[52:53], vcc, v46, %[m1], 0\n\t" \
@@ -229,6 +232,19 @@ __device__ __forceinline__ uint32_t group_code_lanes(uint64_t P, uint32_t x0, ui
 {
     uint32_t pk;
     asm(DNAF_GROUP_ASM
+        : [pk] "=&v"(pk)
+        : [P] "v"(P), [offa] "s"((uint64_t)0), [offb] "s"((uint64_t)PHILOX_M0), [m0] "s"(PHILOX_M0), [m1] "s"(PHILOX_M1), [x0] "v"(x0), [x1] "v"(x1),
+          [x2] "v"(x2), [x3] "v"(x3), [t0] "v"(t0), DNAF_GROUP_KEYS(k)
+        : DNAF_GROUP_CLOBBERS);
+    return pk;
+}
+
+// group_code_lanes with P = M0 * g (the doubling is the shift of the sequence's first instruction: one instruction less
+// for a caller that has g, not 2 g, in a register)
+__device__ __forceinline__ uint32_t group_code_lanes_g(uint64_t P, uint32_t x0, uint32_t x1, uint32_t x2, uint32_t x3, uint32_t t0, const RowKeys& k)
+{
+    uint32_t pk;
+    asm(DNAF_GROUP_HEAD("1") DNAF_GROUP_BODY
         : [pk] "=&v"(pk)
         : [P] "v"(P), [offa] "s"((uint64_t)0), [offb] "s"((uint64_t)PHILOX_M0), [m0] "s"(PHILOX_M0), [m1] "s"(PHILOX_M1), [x0] "v"(x0), [x1] "v"(x1),
           [x2] "v"(x2), [x3] "v"(x3), [t0] "v"(t0), DNAF_GROUP_KEYS(k)
