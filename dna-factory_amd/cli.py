@@ -240,8 +240,8 @@ BED_MAGIC = bytes([0x6C, 0x1B, 0x01])  # PLINK 1 .bed, SNP-major
 def write_vcf(path, header, st, tb, seed, rng, devices, compresslevel, tile_rows=0, threads=0, host_bgzf=False,
               mt_state=None, chunk_restart=False, bed_path=None, workers=1):
     """population.vcf.gz = header + one body line per SNP (output_vcf_population, pop_factory.py:385-415).
-    With several devices each GPU writes its contiguous SNP range to its own BGZF shard; shards are then
-    concatenated (BGZF members are independent), ending with a single EOF block."""
+    With several devices the tiles of SNP rows are dealt round-robin to the GPUs and this thread appends the finished
+    tiles' BGZF members in order (_write_round_robin): the reference's stripe + ordered merge, pop_factory.py:426-469."""
     from . import bgzf
 
     n = len(tb)
