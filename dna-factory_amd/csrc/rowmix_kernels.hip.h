@@ -7,17 +7,17 @@
 // autosome, no forced cells: almost every row) as ONE sequence q = 0, 1, 2, ...: lane l of trip t takes
 // q = 64 t + l, i.e. row q / G, group q mod G.  What differs between rows -- the four folded Philox constants, the
 // threshold, where the row's cells start -- is computed once per row by one lane each and kept in a small LDS table;
-// the Philox group sequence runs with these in vector registers (group_code_lanes, rowrun_kernels.hip.h).  The fixed
-// columns of a row are copied during the trip in which the row begins, so that they reach the L2 next to the cells
-// around them.  Any other row of the run (X / Y / MT, multi-allelic, forced cells) is written by the row-at-a-time
-// code of rowrun_kernels.hip.h in between.
+// the Philox group sequence runs with these in vector registers (group_code_lanes_g, rowrun_kernels.hip.h).  The fixed
+// columns of a row are stored right behind the cells of the trip in which the row begins (the cells leave one trip late,
+// so the columns wait a trip too): a line is written in one burst of stores, not in parts a trip apart.  Any other row of
+// the run (X / Y / MT, multi-allelic, forced cells) is written by the row-at-a-time code of rowrun_kernels.hip.h behind them.
 //
 // Same cell rules, RNG lane mapping and text format as everywhere (pop_factory.py:471-513, rowgen_kernels.hip.h).
 // Used wherever the packed rows are dense (W < 128 words, S <= 2,032): 0.32 instead of 0.13 of the HBM peak at S = 100,
-// 0.40 / 0.21 at 200, 0.48 / 0.30 at 400, 0.50 / 0.43 at 1,000, 0.555 / 0.52 at 2,000 (profiles/r02_shapes.txt; second
-// figure: a wave per row segment, from 1,021 samples a wave per run of whole rows).  The per-lane bookkeeping (row and
-// group of a lane, addresses, the fixed columns) is 30 instructions on top of the 90 of the Philox group; a wave's
-// start-up (its rows' records, then the row table) is a tenth of its life.
+// 0.42 / 0.21 at 200, 0.51 / 0.30 at 400, 0.49-0.55 / 0.43 at 1,000, 0.58-0.60 / 0.52 at 2,000 (profiles/r03_shapes.txt;
+// second figure: a wave per row segment, from 1,021 samples a wave per run of whole rows).  A trip is 103 vector
+// instructions: the 90 of the Philox group and 13 of bookkeeping (the lane's next row and group, one LDS address, table
+// index, store addresses, newline); a wave's start-up (its rows' records, then the row table) is a tenth of its life.
 #pragma once
 #include "rowrun_kernels.hip.h"
 
@@ -217,25 +217,45 @@ __global__ DNAF_MIX_BOUNDS void rowmix_kernel(const GenParams p)
         bool have_prev = false, live_prev = false, last_prev = false;
         u32x4_t w_prev = {0, 0, 0, 0};
         uint32_t off_prev = 0;
-        auto store_prev = [&]() {
-            if (!live_prev) return;
-            uint8_t* dst = run_text + off_prev;
+        auto store_cells = [&](u32x4_t w, uint32_t off, bool live, bool last) {
+            if (!live) return;
+            uint8_t* dst = run_text + off;
             if (FULL4) { // every group is whole, the row's last one ends in a newline
-                w_prev.w += last_prev ? fix : 0u;
-                store_unaligned<16>(dst, &w_prev);
-            } else if (!last_prev) store_unaligned<16>(dst, &w_prev);
+                w.w += last ? fix : 0u;
+                store_unaligned<16>(dst, &w);
+            } else if (!last) store_unaligned<16>(dst, &w);
             else { // the group with the row's last sample: newline instead of the last tab, fewer than 4 samples
-                const uint32_t w0 = w_prev.x + (nvalid_last == 1u ? fix : 0u), w1 = w_prev.y + (nvalid_last == 2u ? fix : 0u);
-                const uint32_t w2 = w_prev.z + (nvalid_last == 3u ? fix : 0u);
+                const uint32_t w0 = w.x + (nvalid_last == 1u ? fix : 0u), w1 = w.y + (nvalid_last == 2u ? fix : 0u);
+                const uint32_t w2 = w.z + (nvalid_last == 3u ? fix : 0u);
                 store_unaligned<4>(dst, &w0);
                 if (nvalid_last > 1u) store_unaligned<4>(dst + 4, &w1);
                 if (nvalid_last > 2u) store_unaligned<4>(dst + 8, &w2);
             }
         };
+        auto store_prev = [&]() { store_cells(w_prev, off_prev, live_prev, last_prev); };
+        // The fixed columns (pop_factory.py:503-507, formatted on the host) of the rows whose first group lies below group
+        // `upto` of the stretch: stored right behind the cells of the trip in which those rows begin -- the cells leave one
+        // trip late (software pipeline), so the columns wait a trip too and the line they share with those cells is written
+        // within one burst of stores, not in two parts a trip apart.
+        auto copy_columns = [&](uint32_t upto) {
+            while (DNAF_MIX_EXP != 2 && next_row < e && next_q < upto) {
+                const uint32_t plen = __builtin_amdgcn_readlane(my_plen, next_row);
+                const uint32_t rel = __builtin_amdgcn_readlane(my_rel, next_row);
+                const uint32_t at = pstride ? next_row * pstride : __builtin_amdgcn_readlane(my_poff, next_row) - pfx0;
+                if (pstride) { // (wave-uniform) at most pstride <= 64 bytes: one predicated byte store, no loop to set up
+                    if (lane < plen) run_text[rel + lane] = pfx[at + lane];
+                } else {
+#pragma clang loop unroll(disable)
+                    for (uint32_t i = lane; i < plen; i += 64) run_text[rel + i] = pfx[at + i];
+                }
+                ++next_row;
+                next_q += G;
+            }
+        };
         // one trip at qb with the current coordinates / table entries (row0, g0, live0, xs0, ts0); those of the trip after it
         // are produced into (row1, ...).  Called alternately with the two register sets, so nothing is copied between trips.
-        auto trip = [&](uint32_t qb, uint32_t row0, uint32_t g0, bool live0, const u32x4_t& xs0, const u32x2_t& ts0, uint32_t& row1,
-                        uint32_t& g1, bool& live1, u32x4_t& xs1, u32x2_t& ts1) {
+        auto trip = [&](uint32_t qb, uint32_t row0, uint32_t g0, bool live0, const u32x4_t& xs0, const u32x2_t& ts0,
+                        uint32_t& row1, uint32_t& g1, bool& live1, u32x4_t& xs1, u32x2_t& ts1) {
             if (qb + 64u < n) { // wave-uniform
                 // one trip on: no division, the lane's group moves by 64 mod G and its row by 64 / G (+ 1 when the group wraps);
                 // four instructions: the borrow of gs - G selects the group and is subtracted from row0 + 64 / G + 1
@@ -251,27 +271,12 @@ __global__ DNAF_MIX_BOUNDS void rowmix_kernel(const GenParams p)
                 xs1 = rtab[2u * row1];
                 ts1 = *reinterpret_cast<LDS_PTR(u32x2_t)>(rtab + 2u * row1 + 1u);
             }
-            if (TEXT && pfx_cached) {
-                // fixed columns of the rows that begin in this trip (pop_factory.py:503-507, formatted on the host)
-                while (DNAF_MIX_EXP == 0 && next_row < e && next_q < qb + 64u) {
-                    const uint32_t plen = __builtin_amdgcn_readlane(my_plen, next_row);
-                    const uint32_t rel = __builtin_amdgcn_readlane(my_rel, next_row);
-                    const uint32_t at = pstride ? next_row * pstride : __builtin_amdgcn_readlane(my_poff, next_row) - pfx0;
-                    if (pstride) { // (wave-uniform) at most pstride <= 64 bytes: one predicated byte copy, no loop to set up
-                        if (lane < plen) run_text[rel + lane] = pfx[at + lane];
-                    } else {
-#pragma clang loop unroll(disable)
-                        for (uint32_t i = lane; i < plen; i += 64) run_text[rel + i] = pfx[at + i];
-                    }
-                    ++next_row;
-                    next_q += G;
-                }
-            }
             const uint64_t P = (uint64_t)PHILOX_M0 * g0;
             uint32_t pk = group_code_lanes_g(P, xs0.x, xs0.y, xs0.z, xs0.w, ts0.x, keys);
             const bool last = g0 == G - 1u;
             if (TEXT) {
                 if (have_prev) store_prev();
+                if (pfx_cached) copy_columns(qb);
                 w_prev = c.lut[pk & 0xFFu];
                 off_prev = ts0.y + 16u * g0;
                 live_prev = live0;
@@ -294,6 +299,7 @@ __global__ DNAF_MIX_BOUNDS void rowmix_kernel(const GenParams p)
             }
         }
         if (TEXT && have_prev) store_prev();
+        if (TEXT && pfx_cached) copy_columns(n);
         if (PACKED && g_stop > G) { // pad bytes of the stretch's packed rows (at most 3 per row)
             const uint32_t npad = g_stop - G;
             for (uint32_t i = lane; i < (e - r) * npad; i += 64u) {
