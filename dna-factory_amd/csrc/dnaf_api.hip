@@ -55,6 +55,7 @@ struct dnaf_ctx {
     uint32_t* d_counts = nullptr;
     uint64_t counts_cap = 0;
     uint32_t* d_xoff = nullptr;
+    uint32_t* d_xgroup = nullptr;      // [G] X rows, per group: cell offset | bytes << 16 | male nibble << 24 (rowmix_kernel)
     std::vector<uint8_t> h_flags;
 
     // forced set
@@ -143,6 +144,8 @@ struct dnaf_ctx {
     uint32_t seg_iters = 32;
     bool force_segments = false;     // DNAF_FORCE_SEGMENTS=1: always the segment form of the kernel (A/B runs, tests)
     uint64_t min_run_waves = 8192;   // fewer runs than this and long rows: the segment form fills the GPU better
+    uint32_t mix_x_max_groups = 160; // DNAF_MIX_X_MAX_GROUPS
+    bool no_mix_x = false;           // DNAF_NO_MIX_X: X rows of short-row shapes a row at a time (tests / A-B)
     uint32_t force_rpw = 0;          // DNAF_ROWS_PER_WAVE: rows per wave of the line-owning form (tests)
     bool no_rowmix = false;          // DNAF_NO_ROWMIX=1: never the short-row form (A/B runs)
     uint32_t mix_max_groups = 509;   // rows of fewer groups than this take the short-row form: every shape with a dense packed pitch
@@ -217,6 +220,8 @@ int dnaf_create(int device, dnaf_ctx** out)
     if (const char* s = getenv("DNAF_NO_ROWMIX")) c->no_rowmix = atoi(s) != 0;
     if (const char* s = getenv("DNAF_MIX_MAX_GROUPS")) c->mix_max_groups = std::min<uint32_t>((uint32_t)strtoul(s, nullptr, 10), dnaf::MIX_MAX_GROUPS);
     if (const char* s = getenv("DNAF_RUN_LDS_PAD")) c->run_lds_pad = (uint32_t)std::min<unsigned long long>(strtoull(s, nullptr, 10), 48u << 10);
+    if (const char* s = getenv("DNAF_NO_MIX_X")) c->no_mix_x = atoi(s) != 0;
+    if (const char* s = getenv("DNAF_MIX_X_MAX_GROUPS")) c->mix_x_max_groups = (uint32_t)strtoul(s, nullptr, 10);
     if (const char* s = getenv("DNAF_ROWS_PER_WAVE")) c->force_rpw = (uint32_t)std::min<unsigned long long>(strtoull(s, nullptr, 10), 1u << 20);
     if (const char* s = getenv("DNAF_SEG_ITERS")) {
         int v = atoi(s);
@@ -234,6 +239,7 @@ int dnaf_destroy(dnaf_ctx* c)
     dev_free(c->d_male_nib);
     dev_free(c->d_ctrl2);
     dev_free(c->d_xoff);
+    dev_free(c->d_xgroup);
     dev_free(c->d_forced);
     dev_free(c->d_recs);
     dev_free(c->d_prefix);
@@ -289,6 +295,7 @@ int dnaf_set_samples(dnaf_ctx* c, const uint8_t* flags, uint64_t n_samples)
     dev_free(c->d_male_nib);
     dev_free(c->d_ctrl2);
     dev_free(c->d_xoff);
+    dev_free(c->d_xgroup);
     c->S = (uint32_t)n_samples;
     c->G = (c->S + 3u) / 4u;
     c->W = (c->S + 15u) / 16u;
@@ -321,6 +328,13 @@ int dnaf_set_samples(dnaf_ctx* c, const uint8_t* flags, uint64_t n_samples)
     HIP_TRY(c, hipMalloc((void**)&c->d_xoff, xoff.size() * sizeof(uint32_t)));
     HIP_TRY(c, hipMemcpy(c->d_male_nib, nib.data(), nib.size(), hipMemcpyHostToDevice));
     HIP_TRY(c, hipMemcpy(c->d_xoff, xoff.data(), xoff.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    {
+        // what the short-row kernel needs of an X row's group in one word (used while rows are short: offsets below 64 KiB)
+        std::vector<uint32_t> xg(c->G ? c->G : 1, 0);
+        for (uint32_t g = 0; g < c->G; ++g) xg[g] = (xoff[g] & 0xFFFFu) | (((xoff[g + 1] - xoff[g]) & 31u) << 16) | ((uint32_t)nib[g] << 24);
+        HIP_TRY(c, hipMalloc((void**)&c->d_xgroup, xg.size() * sizeof(uint32_t)));
+        HIP_TRY(c, hipMemcpy(c->d_xgroup, xg.data(), xg.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    }
     c->have_samples = true;
     return DNAF_OK;
 }
@@ -814,6 +828,10 @@ int dnaf_generate(dnaf_ctx* c, uint64_t row_begin, uint64_t n_rows, uint32_t wha
         p.mix_gmagic = (uint32_t)std::min<uint64_t>(0x100000000ull / c->G, 0xFFFFFFFFull);
         p.mix_step_rows = 64u / c->G;
         p.mix_step_groups = 64u % c->G;
+        // X rows in the lane-spanning trips while a row is shorter than about two trips and a half (S <= 640): +6 % at 200 samples,
+        // +1.5 % at 400, nothing to gain at 2,000, where a row fills its own trips (profiles/r03_shapes.txt)
+        p.mix_x_rows = (!c->no_mix_x && c->G <= c->mix_x_max_groups) ? 1u : 0u;
+        p.xgroup = c->d_xgroup;
     }
     // Two forms of the kernel.  Rows of at least 256 groups in a range with enough rows to fill the GPU one run per wave:
     // the line-owning form (rowrun_kernels.hip.h), a wave per run of whole rows, every 128-byte line of the text has one
@@ -867,14 +885,23 @@ int dnaf_generate(dnaf_ctx* c, uint64_t row_begin, uint64_t n_rows, uint32_t wha
     const dim3 grid((uint32_t)blocks), block(256);
     if (use_mix) {
         const bool full4 = c->S % 4u == 0u;
-        if (what == (DNAF_OUT_TEXT | DNAF_OUT_PACKED)) {
-            if (full4) hipLaunchKernelGGL((dnaf::rowmix_kernel<true, true, true>), grid, block, 0, c->stream, p);
-            else hipLaunchKernelGGL((dnaf::rowmix_kernel<true, true, false>), grid, block, 0, c->stream, p);
-        } else if (what == DNAF_OUT_TEXT) {
-            if (full4) hipLaunchKernelGGL((dnaf::rowmix_kernel<true, false, true>), grid, block, 0, c->stream, p);
-            else hipLaunchKernelGGL((dnaf::rowmix_kernel<true, false, false>), grid, block, 0, c->stream, p);
-        } else if (full4) hipLaunchKernelGGL((dnaf::rowmix_kernel<false, true, true>), grid, block, 0, c->stream, p);
-        else hipLaunchKernelGGL((dnaf::rowmix_kernel<false, true, false>), grid, block, 0, c->stream, p);
+        const uint32_t form = (what == (DNAF_OUT_TEXT | DNAF_OUT_PACKED) ? 0u : what == DNAF_OUT_TEXT ? 4u : 8u) | (full4 ? 2u : 0u) | (p.mix_x_rows ? 1u : 0u);
+#define DNAF_MIX_LAUNCH(T, P, F, X) hipLaunchKernelGGL((dnaf::rowmix_kernel<T, P, F, X>), grid, block, 0, c->stream, p)
+        switch (form) { // text? packed? whole groups only? X rows in the trips?
+        case 0: DNAF_MIX_LAUNCH(true, true, false, false); break;
+        case 1: DNAF_MIX_LAUNCH(true, true, false, true); break;
+        case 2: DNAF_MIX_LAUNCH(true, true, true, false); break;
+        case 3: DNAF_MIX_LAUNCH(true, true, true, true); break;
+        case 4: DNAF_MIX_LAUNCH(true, false, false, false); break;
+        case 5: DNAF_MIX_LAUNCH(true, false, false, true); break;
+        case 6: DNAF_MIX_LAUNCH(true, false, true, false); break;
+        case 7: DNAF_MIX_LAUNCH(true, false, true, true); break;
+        case 8: DNAF_MIX_LAUNCH(false, true, false, false); break;
+        case 9: DNAF_MIX_LAUNCH(false, true, false, true); break;
+        case 10: DNAF_MIX_LAUNCH(false, true, true, false); break;
+        default: DNAF_MIX_LAUNCH(false, true, true, true); break;
+        }
+#undef DNAF_MIX_LAUNCH
     } else if (use_runs) {
         // the cap on workgroups per CU pays for long rows (a wave's passes get closer in time); waves that walk several
         // short rows have more per-row latency to cover and want the full occupancy (S = 4,000: 0.61 without, 0.57 with)

@@ -57,6 +57,8 @@ struct GenParams {
     const uint8_t* prefix_fixed; // [table rows][prefix_stride] the rows' fixed columns at a fixed stride
     uint32_t mix_gmagic;       // rowmix_kernel: min(floor(2^32 / G), 2^32 - 1), for q / G by one multiply-high (divmod_small)
     uint32_t mix_step_rows, mix_step_groups; // rowmix_kernel: a trip ahead = 64 groups = 64 / G rows + 64 mod G groups
+    uint32_t mix_x_rows;       // rowmix_kernel: unforced biallelic X rows ride in the lane-spanning trips too (xgroup is set)
+    const uint32_t* xgroup;    // [G] per group for X rows: cell offset | bytes << 16 | male nibble << 24 (dnaf_set_samples)
 };
 
 // RNG row (relative to rng_row0) of table row j.  rng_div > 1 reproduces the reference's forked workers, which all draw

@@ -20,6 +20,7 @@
 // index, store addresses, newline); a wave's start-up (its rows' records, then the row table) is a tenth of its life.
 #pragma once
 #include "rowrun_kernels.hip.h"
+#include <type_traits>
 
 namespace dnaf {
 
@@ -73,7 +74,9 @@ __device__ unsigned long long mix_prof[16];
 #endif
 
 // FULL4: the sample count is a multiple of 4 (every group whole): the row's last group needs only its newline
-template <bool TEXT, bool PACKED, bool FULL4>
+// XMIX: unforced biallelic X rows ride in the lane-spanning trips too (short rows: GenParams::mix_x_rows); otherwise the
+// kernel holds no code for that (the second set of trips costs 1.5 % at 2,000 samples even when it never runs)
+template <bool TEXT, bool PACKED, bool FULL4, bool XMIX>
 __global__ DNAF_MIX_BOUNDS void rowmix_kernel(const GenParams p)
 {
 #ifdef DNAF_MIX_PROFILE
@@ -88,13 +91,19 @@ __global__ DNAF_MIX_BOUNDS void rowmix_kernel(const GenParams p)
     __shared__ uint8_t lds_pad[DNAF_MIX_LDS_PAD]; // occupancy experiments: fewer workgroups per CU
     if (p.n_rows == ~0ull) lds_pad[threadIdx.x] = 1;
 #endif
+    // per group of 4 samples, for X rows (the same for every X row): byte offset of the group's cells in the row's cell
+    // stream (bits 0-15), how many bytes they take (16-20: 2 per haploid male cell, 4 per diploid one; the row's last group
+    // only its samples), which of the four are male (24-27).  Made on the host (dnaf_set_samples).
+    __shared__ uint32_t xg_tab[XMIX ? MIX_MAX_GROUPS + 3 : 1];
+    if (XMIX)
+        for (uint32_t t = threadIdx.x; t < p.G; t += 256u) xg_tab[t] = p.xgroup[t];
     if (TEXT) {
         const uint32_t t = threadIdx.x;
         const u32x4_t e = {CELL00 + (t & 1u) + ((t & 2u) << 15), CELL00 + ((t >> 2) & 1u) + ((t & 8u) << 13),
                            CELL00 + ((t >> 4) & 1u) + ((t & 32u) << 11), CELL00 + ((t >> 6) & 1u) + ((t & 128u) << 9)};
         cell_lut[t] = e;
-        __syncthreads();
     }
+    __syncthreads();
     const uint32_t lane_id = threadIdx.x & 63u;
     MIX_STAMP(0); // cell table + barrier
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -148,6 +157,9 @@ __global__ DNAF_MIX_BOUNDS void rowmix_kernel(const GenParams p)
     }
     MIX_STAMP(1); // records loaded, row table written
     const uint64_t ord_mask = __ballot(ordinary);
+    // unforced biallelic X rows: the same trips with the cells' widths and places from xg_tab (X rows come in long runs: a
+    // sorted table has them in one block, 5 % of a genome's rows)
+    const uint64_t x_mask = XMIX ? __ballot(lane_id < nrun && myrec.cls == 1u && myrec.n_alleles == 2 && myrec.slot < 0) : 0ull;
     const uint32_t pfx0 = __builtin_amdgcn_readlane(my_poff, 0);
     const uint32_t pfx_bytes = __builtin_amdgcn_readlane(my_poff + my_plen, nrun - 1u) - pfx0;
     const bool pfx_cached = TEXT && (pstride != 0u || pfx_bytes <= MIX_PFX_BYTES) && DNAF_MIX_EXP != 1;
@@ -172,16 +184,18 @@ __global__ DNAF_MIX_BOUNDS void rowmix_kernel(const GenParams p)
     asm volatile("" : "+v"(neg_step));
     const uint32_t fix = 0x0A000000u - 0x09000000u; // '\n' instead of the last '\t'
 
+    auto run_stretches = [&](auto x_kind, const uint64_t kind_mask) {
+    constexpr bool XROW = decltype(x_kind)::value;
     uint32_t r = 0;
     while (r < nrun) {
         uint32_t lane = lane_id; // an opaque copy per stretch: keeps lane-derived values out of registers across the loop
         asm volatile("" : "+v"(lane));
-        if (!((ord_mask >> r) & 1ull)) { // any other kind of row: after the stretches, below
+        if (!((kind_mask >> r) & 1ull)) { // any other kind of row: in another pass, or after the stretches, below
             ++r;
             continue;
         }
-        // the stretch of ordinary rows [r, e)
-        const uint64_t rest = ~(ord_mask >> r);
+        // the stretch of rows of this kind [r, e)
+        const uint64_t rest = ~(kind_mask >> r);
         const uint32_t len = rest ? (uint32_t)__builtin_ctzll(rest) : 64u;
         const uint32_t e = min(nrun, r + len);
         const uint32_t n = (e - r) * G; // groups of the stretch
@@ -214,9 +228,10 @@ __global__ DNAF_MIX_BOUNDS void rowmix_kernel(const GenParams p)
         coords(0u, row0, g0, live0);
         u32x4_t xs0 = rtab[2u * row0];
         u32x2_t ts0 = *reinterpret_cast<LDS_PTR(u32x2_t)>(rtab + 2u * row0 + 1u);
+        uint32_t xe0 = XROW ? xg_tab[g0 < G ? g0 : 0u] : 0u; // X rows: the lane's group in xg_tab
         bool have_prev = false, live_prev = false, last_prev = false;
         u32x4_t w_prev = {0, 0, 0, 0};
-        uint32_t off_prev = 0;
+        uint32_t off_prev = 0, xe_prev = 0;
         auto store_cells = [&](u32x4_t w, uint32_t off, bool live, bool last) {
             if (!live) return;
             uint8_t* dst = run_text + off;
@@ -232,7 +247,54 @@ __global__ DNAF_MIX_BOUNDS void rowmix_kernel(const GenParams p)
                 if (nvalid_last > 2u) store_unaligned<4>(dst + 8, &w2);
             }
         };
-        auto store_prev = [&]() { store_cells(w_prev, off_prev, live_prev, last_prev); };
+        // X row: the diploid text of the four cells from the table, the males' cells cut to "a\t" and the cells shifted together
+        // in registers (x_group_from_code, rowrun_kernels.hip.h); the lane stores the first 8 and the last 8 bytes of its run
+        auto store_cells_x = [&](const u32x4_t& w, uint32_t off, uint32_t xe, bool live, bool last) {
+            if (!live) return;
+            const uint32_t m = xe >> 24, len = (xe >> 16) & 31u;
+            const bool m0 = m & 1u, m1 = m & 2u, m2 = m & 4u, m3 = m & 8u;
+            const uint32_t c0 = m0 ? (w.x & 0xFFu) | 0x0900u : w.x, c1 = m1 ? (w.y & 0xFFu) | 0x0900u : w.y;
+            const uint32_t c2 = m2 ? (w.z & 0xFFu) | 0x0900u : w.z, c3 = m3 ? (w.w & 0xFFu) | 0x0900u : w.w;
+            uint32_t r0 = c3, r1, r2, r3;
+            r1 = m2 ? r0 >> 16 : r0;
+            r0 = m2 ? (r0 << 16) | c2 : c2;
+            r2 = m1 ? r1 >> 16 : r1;
+            r1 = m1 ? __builtin_amdgcn_alignbit(r1, r0, 16) : r0;
+            r0 = m1 ? (r0 << 16) | c1 : c1;
+            r3 = m0 ? r2 >> 16 : r2;
+            r2 = m0 ? __builtin_amdgcn_alignbit(r2, r1, 16) : r1;
+            r1 = m0 ? __builtin_amdgcn_alignbit(r1, r0, 16) : r0;
+            r0 = m0 ? (r0 << 16) | c0 : c0;
+            uint8_t* dst = run_text + off;
+            if (!FULL4 && last) { // the row's last byte (the tab of its last cell, an odd byte of r0 .. r3) becomes the newline
+                const uint32_t one = (len & 2u) ? 0x100u : 0x1000000u, wi = (len - 1u) >> 2;
+                r0 += wi == 0u ? one : 0u; r1 += wi == 1u ? one : 0u; r2 += wi == 2u ? one : 0u; r3 += wi == 3u ? one : 0u;
+            }
+            if (FULL4 || !last || len >= 8u) { // 8 .. 16 bytes
+                const uint32_t sl = len - 8u;
+                const uint32_t q = sl >> 2, sh = (sl & 2u) << 3;
+                const uint32_t t0 = q == 0u ? r0 : (q == 1u ? r1 : r2);
+                const uint32_t t1 = q == 0u ? r1 : (q == 1u ? r2 : r3);
+                const uint32_t t2 = q == 0u ? r2 : (q == 1u ? r3 : 0u);
+                uint2 head = make_uint2(r0, r1);
+                uint2 tail = make_uint2(__builtin_amdgcn_alignbit(t1, t0, sh), __builtin_amdgcn_alignbit(t2, t1, sh));
+                if (FULL4 && last) { // the row's last byte is a newline; with 8 bytes in all the two stores are the same bytes
+                    tail.y += fix;
+                    if (sl == 0u) head.y += fix;
+                }
+                store_unaligned<8>(dst, &head);
+                store_unaligned<8>(dst + sl, &tail);
+            } else { // the row's last group when it has fewer than 8 bytes (one to three samples): 2, 4 or 6 bytes
+                const uint16_t h0 = (uint16_t)r0, h1 = (uint16_t)(r0 >> 16), h2 = (uint16_t)r1;
+                store_unaligned<2>(dst, &h0);
+                if (len >= 4u) store_unaligned<2>(dst + 2, &h1);
+                if (len >= 6u) store_unaligned<2>(dst + 4, &h2);
+            }
+        };
+        auto store_prev = [&]() {
+            if (XROW) store_cells_x(w_prev, off_prev, xe_prev, live_prev, last_prev);
+            else store_cells(w_prev, off_prev, live_prev, last_prev);
+        };
         // The fixed columns (pop_factory.py:503-507, formatted on the host) of the rows whose first group lies below group
         // `upto` of the stretch: stored right behind the cells of the trip in which those rows begin -- the cells leave one
         // trip late (software pipeline), so the columns wait a trip too and the line they share with those cells is written
@@ -254,8 +316,8 @@ __global__ DNAF_MIX_BOUNDS void rowmix_kernel(const GenParams p)
         };
         // one trip at qb with the current coordinates / table entries (row0, g0, live0, xs0, ts0); those of the trip after it
         // are produced into (row1, ...).  Called alternately with the two register sets, so nothing is copied between trips.
-        auto trip = [&](uint32_t qb, uint32_t row0, uint32_t g0, bool live0, const u32x4_t& xs0, const u32x2_t& ts0,
-                        uint32_t& row1, uint32_t& g1, bool& live1, u32x4_t& xs1, u32x2_t& ts1) {
+        auto trip = [&](uint32_t qb, uint32_t row0, uint32_t g0, bool live0, const u32x4_t& xs0, const u32x2_t& ts0, uint32_t xe0,
+                        uint32_t& row1, uint32_t& g1, bool& live1, u32x4_t& xs1, u32x2_t& ts1, uint32_t& xe1) {
             if (qb + 64u < n) { // wave-uniform
                 // one trip on: no division, the lane's group moves by 64 mod G and its row by 64 / G (+ 1 when the group wraps);
                 // four instructions: the borrow of gs - G selects the group and is subtracted from row0 + 64 / G + 1
@@ -270,6 +332,7 @@ __global__ DNAF_MIX_BOUNDS void rowmix_kernel(const GenParams p)
                 live1 = row1 < e; // the groups of the stretch's rows are all live, those of "rows" past it are not
                 xs1 = rtab[2u * row1];
                 ts1 = *reinterpret_cast<LDS_PTR(u32x2_t)>(rtab + 2u * row1 + 1u);
+                if (XROW) xe1 = xg_tab[g1];
             }
             const uint64_t P = (uint64_t)PHILOX_M0 * g0;
             uint32_t pk = group_code_lanes_g(P, xs0.x, xs0.y, xs0.z, xs0.w, ts0.x, keys);
@@ -278,24 +341,31 @@ __global__ DNAF_MIX_BOUNDS void rowmix_kernel(const GenParams p)
                 if (have_prev) store_prev();
                 if (pfx_cached) copy_columns(qb);
                 w_prev = c.lut[pk & 0xFFu];
-                off_prev = ts0.y + 16u * g0;
+                off_prev = XROW ? ts0.y + (xe0 & 0xFFFFu) : ts0.y + 16u * g0;
+                xe_prev = xe0;
                 live_prev = live0;
                 last_prev = last;
                 have_prev = true;
             }
             if (PACKED && live0) {
+                if (XROW) { // haploid: no second allele (male bit k -> bit 2k + 1 cleared)
+                    const uint32_t m = xe0 >> 24;
+                    uint32_t sp = (m | (m << 2)) & 0x33u;
+                    sp = (sp | (sp << 1)) & 0x55u;
+                    pk &= ~(sp << 1);
+                }
                 if (last) pk &= (1u << (2u * nvalid_last)) - 1u; // codes of samples past the end stay 0
                 packed_run[row0 * pitch32 + g0] = (uint8_t)pk;   // 32-bit offsets from the run's first packed byte
             }
         };
         {
-            uint32_t row1 = row0, g1 = g0;
+            uint32_t row1 = row0, g1 = g0, xe1 = xe0;
             bool live1 = false;
             u32x4_t xs1 = xs0;
             u32x2_t ts1 = ts0;
             for (uint32_t qb = 0; qb < n; qb += 128u) {
-                trip(qb, row0, g0, live0, xs0, ts0, row1, g1, live1, xs1, ts1);
-                if (qb + 64u < n) trip(qb + 64u, row1, g1, live1, xs1, ts1, row0, g0, live0, xs0, ts0);
+                trip(qb, row0, g0, live0, xs0, ts0, xe0, row1, g1, live1, xs1, ts1, xe1);
+                if (qb + 64u < n) trip(qb + 64u, row1, g1, live1, xs1, ts1, xe1, row0, g0, live0, xs0, ts0, xe0);
             }
         }
         if (TEXT && have_prev) store_prev();
@@ -309,11 +379,14 @@ __global__ DNAF_MIX_BOUNDS void rowmix_kernel(const GenParams p)
         }
         r = e;
     }
+    };
+    run_stretches(std::false_type{}, ord_mask);
+    if (XMIX && x_mask) run_stretches(std::true_type{}, x_mask); // (wave-uniform)
     // The rows of any other kind (X / Y / MT, multi-allelic, forced cells), a row at a time by the code of
     // rowrun_kernels.hip.h, whole, with this wave's own first and last bytes.  In a loop of their own behind the stretches
     // rather than between them: as a branch inside the loop above, this rare path's live values pushed the trip loop's
     // scalars out of their registers (it reloaded them with v_readlane every trip).
-    for (uint64_t left = ~ord_mask & (nrun >= 64u ? ~0ull : (1ull << nrun) - 1ull); left; left &= left - 1ull) {
+    for (uint64_t left = ~(ord_mask | x_mask) & (nrun >= 64u ? ~0ull : (1ull << nrun) - 1ull); left; left &= left - 1ull) {
         const uint32_t ro = (uint32_t)__builtin_ctzll(left);
         uint32_t lane = lane_id;
         asm volatile("" : "+v"(lane));

@@ -346,6 +346,8 @@ def test_short_row_kernel_fuzz(RowGenerator, oracle, monkeypatch, rpw):
     samples, pad bytes in the packed rows), stretches of ordinary rows broken by X / Y / MT, multi-allelic and forced
     rows."""
     monkeypatch.setenv("DNAF_ROWS_PER_WAVE", str(rpw))
+    if rpw != 1:  # X rows in the lane-spanning trips at every sample count (by default only up to 640 samples)
+        monkeypatch.setenv("DNAF_MIX_X_MAX_GROUPS", "508")
     rs = np.random.RandomState(4000 + rpw)
     pools = [range(1, 9), range(9, 70), range(190, 270), range(500, 530), range(1000, 1030), range(2017, 2033)]
     for case in range(24):
@@ -353,6 +355,33 @@ def test_short_row_kernel_fuzz(RowGenerator, oracle, monkeypatch, rpw):
         n_rows = int(rs.randint(1, 200 if S < 300 else 90))
         snps, samples = random_case(rs, n_rows, S, p_sex_chrom=0.15 if case % 2 else 0.4, n_del=3 if case % 3 else 0)
         check_case(RowGenerator, oracle, snps, samples, seed=int(rs.randint(0, 2**31)), rng_row0=int(rs.randint(0, 1000)))
+
+
+@pytest.mark.parametrize("S", [1, 3, 6, 50, 199, 200, 201, 202, 1001, 2032])
+def test_runs_of_x_rows_in_the_short_row_form(RowGenerator, oracle, monkeypatch, S):
+    """A sorted table holds its X rows in one block: whole runs of them go through the lane-spanning trips of
+    rowmix_kernel with the cells' places and widths from the per-group table (all-male, all-female and mixed sample tables;
+    sample counts with every size of last group; an autosome row, a multi-allelic X row and a forced X row break the run).
+    The row-at-a-time path (DNAF_NO_MIX_X=1) writes the same bytes."""
+    rs = np.random.RandomState(9000 + S)
+    n_rows = 260 if S < 300 else 40
+    snps, samples = random_case(rs, n_rows, S, p_sex_chrom=0.0, n_del=2)
+    snps = [(i, "X" if k % 37 != 5 else ch, pos, tu) for k, (i, ch, pos, tu) in enumerate(snps)]
+    for sexes in ("mixed", "male", "female"):
+        sm = [(sex if sexes == "mixed" else (1 if sexes == "male" else 2), ctrl, car) for (sex, ctrl, car) in samples]
+        outs = []
+        monkeypatch.setenv("DNAF_MIX_X_MAX_GROUPS", "508")  # (the library's own limit is lower: long rows gain nothing)
+        for no_x in ("0", "1"):
+            monkeypatch.setenv("DNAF_NO_MIX_X", no_x)
+            with RowGenerator(device=0, seed=77 + S) as g:
+                g.set_samples(sm)
+                g.set_snps(snps)
+                t, off, p = g.generate()
+                assert g.ctx.last_kernel() == "rowmix_kernel"
+                outs.append((t.tobytes(), off.tobytes(), p.tobytes()))
+        assert outs[0] == outs[1], sexes
+        want_text, _, want_packed = oracle_run(oracle, snps, sm, 77 + S)
+        assert outs[0][0] == want_text and outs[0][2] == want_packed.tobytes(), sexes
 
 
 @pytest.mark.parametrize("share_long", [0.1, 1.0])
