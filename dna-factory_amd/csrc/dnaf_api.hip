@@ -144,7 +144,7 @@ struct dnaf_ctx {
     uint32_t seg_iters = 32;
     bool force_segments = false;     // DNAF_FORCE_SEGMENTS=1: always the segment form of the kernel (A/B runs, tests)
     uint64_t min_run_waves = 8192;   // fewer runs than this and long rows: the segment form fills the GPU better
-    uint32_t mix_x_max_groups = 160; // DNAF_MIX_X_MAX_GROUPS
+    uint32_t mix_x_max_groups = 512; // DNAF_MIX_X_MAX_GROUPS (tests / A-B): X, Y, MT rows in the short-row kernel's trips up to this many groups
     bool no_mix_x = false;           // DNAF_NO_MIX_X: X rows of short-row shapes a row at a time (tests / A-B)
     uint32_t force_rpw = 0;          // DNAF_ROWS_PER_WAVE: rows per wave of the line-owning form (tests)
     bool no_rowmix = false;          // DNAF_NO_ROWMIX=1: never the short-row form (A/B runs)
@@ -828,8 +828,8 @@ int dnaf_generate(dnaf_ctx* c, uint64_t row_begin, uint64_t n_rows, uint32_t wha
         p.mix_gmagic = (uint32_t)std::min<uint64_t>(0x100000000ull / c->G, 0xFFFFFFFFull);
         p.mix_step_rows = 64u / c->G;
         p.mix_step_groups = 64u % c->G;
-        // X rows in the lane-spanning trips while a row is shorter than about two trips and a half (S <= 640): +6 % at 200 samples,
-        // +1.5 % at 400, nothing to gain at 2,000, where a row fills its own trips (profiles/r03_shapes.txt)
+        // X / Y / MT rows in the lane-spanning trips: +12 % at 200 samples, +7 % at 400, +3 % at 1,000, within the noise at 1,600 and
+        // 2,000 (profiles/r03_shapes.txt)
         p.mix_x_rows = (!c->no_mix_x && c->G <= c->mix_x_max_groups) ? 1u : 0u;
         p.xgroup = c->d_xgroup;
     }

@@ -160,6 +160,9 @@ __global__ DNAF_MIX_BOUNDS void rowmix_kernel(const GenParams p)
     // unforced biallelic X rows: the same trips with the cells' widths and places from xg_tab (X rows come in long runs: a
     // sorted table has them in one block, 5 % of a genome's rows)
     const uint64_t x_mask = XMIX ? __ballot(lane_id < nrun && myrec.cls == 1u && myrec.n_alleles == 2 && myrec.slot < 0) : 0ull;
+    // and Y / MT rows: four haploid cells of two bytes per group, '.' for a female on Y (pop_factory.py:481-484)
+    const uint64_t y_mask = XMIX ? __ballot(lane_id < nrun && myrec.cls == 2u && myrec.n_alleles == 2 && myrec.slot < 0) : 0ull;
+    const uint64_t mt_mask = XMIX ? __ballot(lane_id < nrun && myrec.cls == 3u && myrec.n_alleles == 2 && myrec.slot < 0) : 0ull;
     const uint32_t pfx0 = __builtin_amdgcn_readlane(my_poff, 0);
     const uint32_t pfx_bytes = __builtin_amdgcn_readlane(my_poff + my_plen, nrun - 1u) - pfx0;
     const bool pfx_cached = TEXT && (pstride != 0u || pfx_bytes <= MIX_PFX_BYTES) && DNAF_MIX_EXP != 1;
@@ -184,8 +187,10 @@ __global__ DNAF_MIX_BOUNDS void rowmix_kernel(const GenParams p)
     asm volatile("" : "+v"(neg_step));
     const uint32_t fix = 0x0A000000u - 0x09000000u; // '\n' instead of the last '\t'
 
-    auto run_stretches = [&](auto x_kind, const uint64_t kind_mask) {
-    constexpr bool XROW = decltype(x_kind)::value;
+    // kind 0: biallelic autosome rows; 1: X rows; 2: Y rows (all_haploid false: '.' for females) and MT rows (true)
+    auto run_stretches = [&](auto kind_tag, const uint64_t kind_mask, const bool all_haploid) {
+    constexpr int KIND = decltype(kind_tag)::value;
+    constexpr bool XROW = KIND == 1, HAPLOID = KIND == 2;
     uint32_t r = 0;
     while (r < nrun) {
         uint32_t lane = lane_id; // an opaque copy per stretch: keeps lane-derived values out of registers across the loop
@@ -228,7 +233,7 @@ __global__ DNAF_MIX_BOUNDS void rowmix_kernel(const GenParams p)
         coords(0u, row0, g0, live0);
         u32x4_t xs0 = rtab[2u * row0];
         u32x2_t ts0 = *reinterpret_cast<LDS_PTR(u32x2_t)>(rtab + 2u * row0 + 1u);
-        uint32_t xe0 = XROW ? xg_tab[g0 < G ? g0 : 0u] : 0u; // X rows: the lane's group in xg_tab
+        uint32_t xe0 = KIND ? xg_tab[g0 < G ? g0 : 0u] : 0u; // X / Y rows: the lane's group in xg_tab
         bool have_prev = false, live_prev = false, last_prev = false;
         u32x4_t w_prev = {0, 0, 0, 0};
         uint32_t off_prev = 0, xe_prev = 0;
@@ -291,8 +296,28 @@ __global__ DNAF_MIX_BOUNDS void rowmix_kernel(const GenParams p)
                 if (len >= 6u) store_unaligned<2>(dst + 4, &h2);
             }
         };
+        // Y / MT row: four cells of two bytes, "a\t" for a haploid sample (its first allele), ".\t" for a female on Y
+        auto store_cells_h = [&](const u32x4_t& w, uint32_t off, uint32_t xe, bool live, bool last) {
+            if (!live) return;
+            const uint32_t m = all_haploid ? 0xFu : xe >> 24;
+            const uint32_t c0 = (m & 1u) ? (w.x & 0xFFu) | 0x0900u : 0x092Eu, c1 = (m & 2u) ? (w.y & 0xFFu) | 0x0900u : 0x092Eu;
+            const uint32_t c2 = (m & 4u) ? (w.z & 0xFFu) | 0x0900u : 0x092Eu, c3 = (m & 8u) ? (w.w & 0xFFu) | 0x0900u : 0x092Eu;
+            uint8_t* dst = run_text + off;
+            if (FULL4 || !last) {
+                uint2 d = make_uint2(c0 | (c1 << 16), c2 | (c3 << 16));
+                if (FULL4 && last) d.y += fix;
+                store_unaligned<8>(dst, &d);
+            } else { // the row's last group: one to three samples, the last one's tab is the newline
+                const uint16_t h0 = (uint16_t)(c0 + (nvalid_last == 1u ? 0x100u : 0u)), h1 = (uint16_t)(c1 + (nvalid_last == 2u ? 0x100u : 0u));
+                const uint16_t h2 = (uint16_t)(c2 + 0x100u);
+                store_unaligned<2>(dst, &h0);
+                if (nvalid_last > 1u) store_unaligned<2>(dst + 2, &h1);
+                if (nvalid_last > 2u) store_unaligned<2>(dst + 4, &h2);
+            }
+        };
         auto store_prev = [&]() {
             if (XROW) store_cells_x(w_prev, off_prev, xe_prev, live_prev, last_prev);
+            else if (HAPLOID) store_cells_h(w_prev, off_prev, xe_prev, live_prev, last_prev);
             else store_cells(w_prev, off_prev, live_prev, last_prev);
         };
         // The fixed columns (pop_factory.py:503-507, formatted on the host) of the rows whose first group lies below group
@@ -332,7 +357,7 @@ __global__ DNAF_MIX_BOUNDS void rowmix_kernel(const GenParams p)
                 live1 = row1 < e; // the groups of the stretch's rows are all live, those of "rows" past it are not
                 xs1 = rtab[2u * row1];
                 ts1 = *reinterpret_cast<LDS_PTR(u32x2_t)>(rtab + 2u * row1 + 1u);
-                if (XROW) xe1 = xg_tab[g1];
+                if (KIND) xe1 = xg_tab[g1];
             }
             const uint64_t P = (uint64_t)PHILOX_M0 * g0;
             uint32_t pk = group_code_lanes_g(P, xs0.x, xs0.y, xs0.z, xs0.w, ts0.x, keys);
@@ -341,18 +366,19 @@ __global__ DNAF_MIX_BOUNDS void rowmix_kernel(const GenParams p)
                 if (have_prev) store_prev();
                 if (pfx_cached) copy_columns(qb);
                 w_prev = c.lut[pk & 0xFFu];
-                off_prev = XROW ? ts0.y + (xe0 & 0xFFFFu) : ts0.y + 16u * g0;
+                off_prev = XROW ? ts0.y + (xe0 & 0xFFFFu) : ts0.y + (HAPLOID ? 8u : 16u) * g0;
                 xe_prev = xe0;
                 live_prev = live0;
                 last_prev = last;
                 have_prev = true;
             }
             if (PACKED && live0) {
-                if (XROW) { // haploid: no second allele (male bit k -> bit 2k + 1 cleared)
-                    const uint32_t m = xe0 >> 24;
+                if (KIND) { // male bit k -> bit 2k
+                    const uint32_t m = (HAPLOID && all_haploid) ? 0xFu : xe0 >> 24;
                     uint32_t sp = (m | (m << 2)) & 0x33u;
                     sp = (sp | (sp << 1)) & 0x55u;
-                    pk &= ~(sp << 1);
+                    if (XROW) pk &= ~(sp << 1); // haploid males: no second allele
+                    else pk &= sp;              // Y / MT: the first allele of the haploid samples, nothing for a female on Y
                 }
                 if (last) pk &= (1u << (2u * nvalid_last)) - 1u; // codes of samples past the end stay 0
                 packed_run[row0 * pitch32 + g0] = (uint8_t)pk;   // 32-bit offsets from the run's first packed byte
@@ -380,13 +406,15 @@ __global__ DNAF_MIX_BOUNDS void rowmix_kernel(const GenParams p)
         r = e;
     }
     };
-    run_stretches(std::false_type{}, ord_mask);
-    if (XMIX && x_mask) run_stretches(std::true_type{}, x_mask); // (wave-uniform)
+    run_stretches(std::integral_constant<int, 0>{}, ord_mask, false);
+    if (XMIX && x_mask) run_stretches(std::integral_constant<int, 1>{}, x_mask, false); // (wave-uniform)
+    if (XMIX && y_mask) run_stretches(std::integral_constant<int, 2>{}, y_mask, false);
+    if (XMIX && mt_mask) run_stretches(std::integral_constant<int, 2>{}, mt_mask, true);
     // The rows of any other kind (X / Y / MT, multi-allelic, forced cells), a row at a time by the code of
     // rowrun_kernels.hip.h, whole, with this wave's own first and last bytes.  In a loop of their own behind the stretches
     // rather than between them: as a branch inside the loop above, this rare path's live values pushed the trip loop's
     // scalars out of their registers (it reloaded them with v_readlane every trip).
-    for (uint64_t left = ~(ord_mask | x_mask) & (nrun >= 64u ? ~0ull : (1ull << nrun) - 1ull); left; left &= left - 1ull) {
+    for (uint64_t left = ~(ord_mask | x_mask | y_mask | mt_mask) & (nrun >= 64u ? ~0ull : (1ull << nrun) - 1ull); left; left &= left - 1ull) {
         const uint32_t ro = (uint32_t)__builtin_ctzll(left);
         uint32_t lane = lane_id;
         asm volatile("" : "+v"(lane));

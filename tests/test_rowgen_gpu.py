@@ -358,15 +358,15 @@ def test_short_row_kernel_fuzz(RowGenerator, oracle, monkeypatch, rpw):
 
 
 @pytest.mark.parametrize("S", [1, 3, 6, 50, 199, 200, 201, 202, 1001, 2032])
-def test_runs_of_x_rows_in_the_short_row_form(RowGenerator, oracle, monkeypatch, S):
-    """A sorted table holds its X rows in one block: whole runs of them go through the lane-spanning trips of
+def test_runs_of_x_y_mt_rows_in_the_short_row_form(RowGenerator, oracle, monkeypatch, S):
+    """A sorted table holds its X, Y and MT rows in blocks: whole runs of them go through the lane-spanning trips of
     rowmix_kernel with the cells' places and widths from the per-group table (all-male, all-female and mixed sample tables;
-    sample counts with every size of last group; an autosome row, a multi-allelic X row and a forced X row break the run).
+    sample counts with every size of last group; autosome rows, multi-allelic and forced rows break the runs).
     The row-at-a-time path (DNAF_NO_MIX_X=1) writes the same bytes."""
     rs = np.random.RandomState(9000 + S)
     n_rows = 260 if S < 300 else 40
     snps, samples = random_case(rs, n_rows, S, p_sex_chrom=0.0, n_del=2)
-    snps = [(i, "X" if k % 37 != 5 else ch, pos, tu) for k, (i, ch, pos, tu) in enumerate(snps)]
+    snps = [(i, ("X", "X", "Y", "MT", "X", "Y")[(k // 9) % 6] if k % 37 != 5 else ch, pos, tu) for k, (i, ch, pos, tu) in enumerate(snps)]
     for sexes in ("mixed", "male", "female"):
         sm = [(sex if sexes == "mixed" else (1 if sexes == "male" else 2), ctrl, car) for (sex, ctrl, car) in samples]
         outs = []
