@@ -523,6 +523,26 @@ __device__ __forceinline__ void x_group_from_code(const SegCtx& c, uint32_t g, u
     }
 }
 
+// The 4 cells of a complete Y / MT group from its packed byte (the second alleles are drawn and dropped like a male's on
+// X): "a\t" for a haploid sample, ".\t" for a female on Y (pop_factory.py:481-484); 8 bytes per lane.
+template <bool TEXT, bool PACKED, bool IS_Y>
+__device__ __forceinline__ void haploid_group_from_code(const SegCtx& c, uint32_t g, uint32_t pk)
+{
+    const uint32_t m = IS_Y ? (uint32_t)c.male_nib[g] : 0xFu;
+    if (TEXT) {
+        const u32x4_t w = c.lut[pk & 0xFFu];
+        const uint32_t c0 = (m & 1u) ? (w.x & 0xFFu) | 0x0900u : 0x092Eu, c1 = (m & 2u) ? (w.y & 0xFFu) | 0x0900u : 0x092Eu;
+        const uint32_t c2 = (m & 4u) ? (w.z & 0xFFu) | 0x0900u : 0x092Eu, c3 = (m & 8u) ? (w.w & 0xFFu) | 0x0900u : 0x092Eu;
+        const uint2 d = make_uint2(c0 | (c1 << 16), c2 | (c3 << 16));
+        store_unaligned<8>(c.cells + 8ull * g, &d);
+    }
+    if (PACKED) {
+        uint32_t sp = (m | (m << 2)) & 0x33u; // male bit k -> bit 2k
+        sp = (sp | (sp << 1)) & 0x55u;
+        c.prow[g] = (uint8_t)(pk & sp); // the first allele of the haploid samples
+    }
+}
+
 // Number of leading groups of a row whose cells begin below cell-stream offset `bytes` (<= 127): those are the
 // groups a line boundary `bytes` into the cell stream can cut.  At most 16 (a group is at least 8 bytes).
 __device__ __forceinline__ uint32_t groups_below(const SegCtx& c, uint32_t cls, uint32_t bytes, uint32_t lane)
@@ -560,6 +580,19 @@ __device__ __forceinline__ void run_row_other(const SegCtx& c, uint32_t cls, uin
             if (gb + lane < g_fast) {
                 if (c.frow) pk = force_code(c, pk, gb + lane);
                 x_group_from_code<TEXT, PACKED>(c, gb + lane, pk);
+            }
+        }
+    } else if (!MULTI) { // Y (cls 2) / MT rows: the hand-written Philox group as well
+        const RowConst rc = make_row_const(c);
+        const RowKeys keys = make_row_keys(c.k0, c.k1);
+        const uint64_t pl = (uint64_t)PHILOX_M0 * (2u * lane);
+        for (; gb < g_fast; gb += 64u) {
+            const uint64_t off = (uint64_t)PHILOX_M0 * (2u * gb);
+            uint32_t pk = group_code(pl, off, off + PHILOX_M0, rc, keys, c.t0);
+            if (gb + lane < g_fast) {
+                if (c.frow) pk = force_code(c, pk, gb + lane); // (a carrier's "1/1": both alleles set; a female on Y stays '.')
+                if (cls == 2u) haploid_group_from_code<TEXT, PACKED, true>(c, gb + lane, pk);
+                else haploid_group_from_code<TEXT, PACKED, false>(c, gb + lane, pk);
             }
         }
     } else if (cls == 2u) {
