@@ -9,12 +9,13 @@
 // threshold, where the row's cells start -- is computed once per row by one lane each and kept in a small LDS table;
 // the Philox group sequence runs with these in vector registers (group_code_lanes_g, rowrun_kernels.hip.h).  The fixed
 // columns of a row are stored right behind the cells of the trip in which the row begins (the cells leave one trip late,
-// so the columns wait a trip too): a line is written in one burst of stores, not in parts a trip apart.  Any other row of
-// the run (X / Y / MT, multi-allelic, forced cells) is written by the row-at-a-time code of rowrun_kernels.hip.h behind them.
+// so the columns wait a trip too): a line is written in one burst of stores, not in parts a trip apart.  Runs of X rows and
+// of Y / MT rows go through trips of the same kind, with the cells' places and widths from a per-group word (xg_tab).  Any
+// other row of the run (multi-allelic, forced cells) is written by the row-at-a-time code of rowrun_kernels.hip.h behind them.
 //
 // Same cell rules, RNG lane mapping and text format as everywhere (pop_factory.py:471-513, rowgen_kernels.hip.h).
-// Used wherever the packed rows are dense (W < 128 words, S <= 2,032): 0.32 instead of 0.13 of the HBM peak at S = 100,
-// 0.42 / 0.21 at 200, 0.51 / 0.30 at 400, 0.49-0.55 / 0.43 at 1,000, 0.58-0.60 / 0.52 at 2,000 (profiles/r03_shapes.txt;
+// Used wherever the packed rows are dense (W < 128 words, S <= 2,032): 0.39-0.42 instead of 0.13 of the HBM peak at S = 100,
+// 0.45-0.49 / 0.21 at 200, 0.53 / 0.30 at 400, 0.52-0.56 / 0.43 at 1,000, 0.58-0.60 / 0.52 at 2,000 (profiles/r03_shapes.txt;
 // second figure: a wave per row segment, from 1,021 samples a wave per run of whole rows).  A trip is 103 vector
 // instructions: the 90 of the Philox group and 13 of bookkeeping (the lane's next row and group, one LDS address, table
 // index, store addresses, newline); a wave's start-up (its rows' records, then the row table) is a tenth of its life.
