@@ -27,7 +27,7 @@ namespace dnaf {
 
 typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
 
-struct MixRow {        // what a lane needs of its row (kept in two LDS arrays: the constants, and threshold + cell start)
+struct MixRow {        // what a lane needs of its row: one 32-byte entry of the wave's LDS table
     uint32_t x0, x1, x2, x3;
     uint32_t t0, cells_rel, pad0, pad1; // cells_rel: the row's first cell byte, relative to the run's first text byte
 };
@@ -75,8 +75,8 @@ __device__ unsigned long long mix_prof[16];
 #endif
 
 // FULL4: the sample count is a multiple of 4 (every group whole): the row's last group needs only its newline
-// XMIX: unforced biallelic X rows ride in the lane-spanning trips too (short rows: GenParams::mix_x_rows); otherwise the
-// kernel holds no code for that (the second set of trips costs 1.5 % at 2,000 samples even when it never runs)
+// XMIX: runs of unforced biallelic X rows, Y rows and MT rows go through lane-spanning trips of their own (GenParams::mix_x_rows);
+// otherwise the kernel holds no code for that (the further sets of trips cost 1.5 % at 2,000 samples even when they never run)
 template <bool TEXT, bool PACKED, bool FULL4, bool XMIX>
 __global__ DNAF_MIX_BOUNDS void rowmix_kernel(const GenParams p)
 {
@@ -94,7 +94,7 @@ __global__ DNAF_MIX_BOUNDS void rowmix_kernel(const GenParams p)
 #endif
     // per group of 4 samples, for X rows (the same for every X row): byte offset of the group's cells in the row's cell
     // stream (bits 0-15), how many bytes they take (16-20: 2 per haploid male cell, 4 per diploid one; the row's last group
-    // only its samples), which of the four are male (24-27).  Made on the host (dnaf_set_samples).
+    // only its samples), which of the four are male (24-27; Y rows use this part only).  Made on the host (dnaf_set_samples).
     __shared__ uint32_t xg_tab[XMIX ? MIX_MAX_GROUPS + 3 : 1];
     if (XMIX)
         for (uint32_t t = threadIdx.x; t < p.G; t += 256u) xg_tab[t] = p.xgroup[t];
@@ -411,7 +411,7 @@ __global__ DNAF_MIX_BOUNDS void rowmix_kernel(const GenParams p)
     if (XMIX && x_mask) run_stretches(std::integral_constant<int, 1>{}, x_mask, false); // (wave-uniform)
     if (XMIX && y_mask) run_stretches(std::integral_constant<int, 2>{}, y_mask, false);
     if (XMIX && mt_mask) run_stretches(std::integral_constant<int, 2>{}, mt_mask, true);
-    // The rows of any other kind (X / Y / MT, multi-allelic, forced cells), a row at a time by the code of
+    // The rows of any other kind (multi-allelic, forced cells; without XMIX also X / Y / MT), a row at a time by the code of
     // rowrun_kernels.hip.h, whole, with this wave's own first and last bytes.  In a loop of their own behind the stretches
     // rather than between them: as a branch inside the loop above, this rare path's live values pushed the trip loop's
     // scalars out of their registers (it reloaded them with v_readlane every trip).
