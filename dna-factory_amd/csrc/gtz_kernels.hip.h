@@ -40,17 +40,24 @@ namespace dnaf {
 constexpr uint32_t GTZ_THREADS = 256;      // one item (64-cell chunk or literal span) per thread: members of long rows (up to 256 items)
 constexpr uint32_t GTZ_THREADS_MANY = 512; // members of short rows: more rows, hence more spans and cut chunks
 constexpr uint32_t GTZ_MAX_WAVES = GTZ_THREADS_MANY / 64;
-constexpr uint32_t GTZ_KEY_CELLS = 5;
+#ifndef DNAF_GTZ_KEY_CELLS
+#define DNAF_GTZ_KEY_CELLS 5
+#endif
+constexpr uint32_t GTZ_KEY_CELLS = DNAF_GTZ_KEY_CELLS; // cells of a table key = the shortest LZ77 match (experiments: 4)
 constexpr uint32_t GTZ_KEYS = 1u << (2 * GTZ_KEY_CELLS);
 #ifndef DNAF_GTZ_SEGS
 #define DNAF_GTZ_SEGS 3
 #endif
 constexpr uint32_t GTZ_SEGS = DNAF_GTZ_SEGS;                 // segments of the member's g space, each with its own key tables
-constexpr uint32_t GTZ_SEG_CELLS = GTZ_SEGS == 4 ? 4096 : 5120; // 4 x 4096 (the last one open-ended) or 3 x 5120
-static_assert(GTZ_SEGS == 3 || GTZ_SEGS == 4, "segments");
+// 3 x 5120 cells (the last segment open-ended); experiments: 4 x 4096, 6 x 2560, 8 x 2048 -- with more, shorter segments the
+// candidates of the segments before lie inside deflate's 32 KiB window (profiles/r03_parse_study.txt)
+constexpr uint32_t GTZ_SEG_CELLS = GTZ_SEGS == 3 ? 5120 : GTZ_SEGS == 4 ? 4096 : GTZ_SEGS == 6 ? 2560 : 2048;
+static_assert(GTZ_SEGS == 3 || GTZ_SEGS == 4 || GTZ_SEGS == 6 || GTZ_SEGS == 8, "segments");
 __device__ __forceinline__ uint32_t gtz_segment(uint32_t g)
 {
-    return GTZ_SEGS == 4 ? min(g >> 12, 3u) : (g >= GTZ_SEG_CELLS ? 1u : 0u) + (g >= 2u * GTZ_SEG_CELLS ? 1u : 0u);
+    if (GTZ_SEGS == 3) return (g >= GTZ_SEG_CELLS ? 1u : 0u) + (g >= 2u * GTZ_SEG_CELLS ? 1u : 0u);
+    if (GTZ_SEGS == 6) return min(g / GTZ_SEG_CELLS, GTZ_SEGS - 1u);
+    return min(g >> (GTZ_SEGS == 4 ? 12 : 11), GTZ_SEGS - 1u);
 }
 constexpr uint32_t GTZ_MAX_ROWS = 16;     // rows overlapping one member
 constexpr uint32_t GTZ_MAX_FAR = 12;      // LZ77 matches recorded per chunk (64 cells / 5)
@@ -446,8 +453,8 @@ __global__ __launch_bounds__(THREADS) GTZ_OCCUPANCY void gtz_encode(const GtzPar
         {
             constexpr uint32_t WPS = WAVES / GTZ_SEGS ? WAVES / GTZ_SEGS : 1u; // waves per segment (256 threads, 3 segments: one, the fourth wave rests)
             const uint32_t wave_ = tid >> 6, lane_ = tid & 63u;
-            const uint32_t q = wave_ / WPS, sub = wave_ - q * WPS;
-            if (q < GTZ_SEGS) {
+            const uint32_t sub = wave_ % WPS;
+            for (uint32_t q = wave_ / WPS; q < GTZ_SEGS; q += WAVES / WPS) { // (more segments than waves: several each, experiments)
                 const uint32_t seg_lo = q * GTZ_SEG_CELLS, seg_hi = q + 1u < GTZ_SEGS ? min(total, seg_lo + GTZ_SEG_CELLS) : total;
                 uint16_t* tab = &s->tab16[(2u * q) * GTZ_KEYS];
                 // "latest": ascending, plain stores; "earliest": descending, plain stores (the last writer is the lowest position)

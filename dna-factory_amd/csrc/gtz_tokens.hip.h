@@ -119,6 +119,13 @@ __device__ __forceinline__ GtzEvents gtz_find_matches(GtzShared* s, uint32_t i, 
 #if DNAF_GTZ_CANDS > 3
             cand[3] = q > 1u ? (uint32_t)s->tab16[(2u * (q - 2u) + 1u) * GTZ_KEYS + key] - 1u : 0xFFFFFFFFu;
 #endif
+#if DNAF_GTZ_CANDS > 4 // (experiments with short segments)
+            cand[4] = q > 1u ? (uint32_t)s->tab16[(2u * (q - 2u)) * GTZ_KEYS + key] : 0xFFFFFFFFu;
+            if (cand[4] == cand[3]) cand[4] = 0xFFFFFFFFu;
+#endif
+#if DNAF_GTZ_CANDS > 5
+            cand[5] = q > 2u ? (uint32_t)s->tab16[(2u * (q - 3u) + 1u) * GTZ_KEYS + key] - 1u : 0xFFFFFFFFu;
+#endif
             const uint32_t room = c.j1 - j;
             // Every candidate alike, in this row or an earlier one: the row of the source from the word map, its bounds
             // in the member and the byte distance from the rows' offsets (byte of position g = 4 g + delta[row]).  The
